@@ -1,0 +1,316 @@
+"""CPU oracle: functional fp32 restatement of the GenConViT ``ed``/``vae`` forward.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``genconvit_amd/`` imports this module;
+only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may, and only as the checker / reported CPU baseline.
+
+Pinning status (see DESIGN.md "Oracle"):
+  * ED Encoder/Decoder, VAE Encoder/Decoder (incl. the reparameterisation quirk),
+    the ED/VAE/GenConViT forward glue (cat order, activations, head) and
+    pred_func's vote are PINNED: ``tests/golden/make_golden.py`` runs the
+    reference's own classes (imported from /root/reference in the build
+    container) on the same synthetic weights and the outputs match this file
+    bit-for-bit; the vectors are committed under ``tests/golden/``.
+  * The ConvNeXt-T / Swin-T arithmetic lives in third-party ``timm==0.6.5``
+    (requirements.txt:5), which is absent here and has no tests in the
+    reference: **parity unpinned** by the reference for that part.  It is
+    restated from the published architecture and
+    cross-checked against the independent Hugging Face ``transformers``
+    implementation of the same architectures (tests/test_oracle.py).
+
+Every function cites the reference lines it follows (paths relative to
+/root/reference).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from genconvit_amd.spec import (CONVNEXT_DEPTHS, CONVNEXT_DIMS, SWIN_DEPTHS, SWIN_DIMS,
+                                SWIN_HEADS)
+
+LN_EPS_CONVNEXT = 1e-6   # timm ConvNeXt LayerNorm/LayerNorm2d eps
+LN_EPS_SWIN = 1e-5       # timm Swin nn.LayerNorm default
+BN_EPS = 1e-5            # nn.BatchNorm2d default, genconvit_vae.py:16
+LEAKY = 0.01             # nn.LeakyReLU default, genconvit_vae.py:17
+
+
+# --------------------------------------------------------------------------- ED AE
+def ed_encoder(sd, x, taps=None):
+    """model/genconvit_ed.py:13-36 — 5x[Conv2d 3x3 s1 p1 -> ReLU -> MaxPool 2x2]."""
+    for li, idx in enumerate((0, 3, 6, 9, 12)):
+        x = F.conv2d(x, sd[f"encoder.features.{idx}.weight"], sd[f"encoder.features.{idx}.bias"],
+                     stride=1, padding=1)
+        x = F.max_pool2d(F.relu(x), kernel_size=2, stride=2)
+        if taps is not None:
+            taps[f"ed_enc{li}"] = x
+    return x
+
+
+def ed_decoder(sd, x, taps=None):
+    """model/genconvit_ed.py:43-61 — 5x[ConvTranspose2d 2x2 s2 -> ReLU]."""
+    for li, idx in enumerate((0, 2, 4, 6, 8)):
+        x = F.relu(F.conv_transpose2d(x, sd[f"decoder.features.{idx}.weight"],
+                                      sd[f"decoder.features.{idx}.bias"], stride=2))
+        if taps is not None:
+            taps[f"ed_dec{li}"] = x
+    return x
+
+
+# --------------------------------------------------------------------------- ConvNeXt-T
+def _ln2d(x, w, b, eps):
+    """timm LayerNorm2d: LN over the channel dim of NCHW (biased var, eps in sqrt)."""
+    return F.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), w, b, eps).permute(0, 3, 1, 2)
+
+
+def convnext_block(sd, p, x):
+    """timm 0.6.5 ConvNeXtBlock.forward: dw7x7 -> LN(NHWC)
+    -> fc1 -> exact GELU -> fc2 -> * gamma -> + shortcut."""
+    c = x.shape[1]
+    y = F.conv2d(x, sd[p + "conv_dw.weight"], sd[p + "conv_dw.bias"], padding=3, groups=c)
+    y = y.permute(0, 2, 3, 1)
+    y = F.layer_norm(y, (c,), sd[p + "norm.weight"], sd[p + "norm.bias"], LN_EPS_CONVNEXT)
+    y = F.linear(y, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])
+    y = F.gelu(y)
+    y = F.linear(y, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    y = y.permute(0, 3, 1, 2)
+    y = y * sd[p + "gamma"].reshape(1, -1, 1, 1)
+    return y + x
+
+
+def convnext_tiny(sd, prefix, x, taps=None):
+    """timm 0.6.5 ``convnext_tiny`` forward: stem -> 4 stages -> (norm_pre=Identity)
+    -> head(global avg pool, LayerNorm2d, flatten, fc).  Called by the reference at
+    model/genconvit_ed.py:82-83 and model/genconvit_vae.py:111-112."""
+    p = prefix
+    x = F.conv2d(x, sd[p + "stem.0.weight"], sd[p + "stem.0.bias"], stride=4)
+    x = _ln2d(x, sd[p + "stem.1.weight"], sd[p + "stem.1.bias"], LN_EPS_CONVNEXT)
+    if taps is not None:
+        taps["stem"] = x
+    for i, depth in enumerate(CONVNEXT_DEPTHS):
+        if i > 0:
+            x = _ln2d(x, sd[p + f"stages.{i}.downsample.0.weight"],
+                      sd[p + f"stages.{i}.downsample.0.bias"], LN_EPS_CONVNEXT)
+            x = F.conv2d(x, sd[p + f"stages.{i}.downsample.1.weight"],
+                         sd[p + f"stages.{i}.downsample.1.bias"], stride=2)
+        for j in range(depth):
+            x = convnext_block(sd, p + f"stages.{i}.blocks.{j}.", x)
+        if taps is not None:
+            taps[f"stage{i}"] = x
+    x = x.mean((2, 3), keepdim=True)
+    x = _ln2d(x, sd[p + "head.norm.weight"], sd[p + "head.norm.bias"], LN_EPS_CONVNEXT)
+    x = torch.flatten(x, 1)
+    return F.linear(x, sd[p + "head.fc.weight"], sd[p + "head.fc.bias"])
+
+
+# --------------------------------------------------------------------------- ED
+def ed_forward(sd, images, taps=None):
+    """GenConViTED.forward, model/genconvit_ed.py:77-88.  cat order is
+    [backbone(recon), backbone(orig)]; ``self.relu`` is exact-erf nn.GELU (:75)."""
+    encimg = ed_encoder(sd, images, taps)
+    decimg = ed_decoder(sd, encimg, taps)
+    x1 = convnext_tiny(sd, "backbone.", decimg)
+    x2 = convnext_tiny(sd, "backbone.", images, taps)
+    x = torch.cat((x1, x2), dim=1)
+    if taps is not None:
+        taps["ed_feat"] = x
+    x = F.gelu(x)
+    x = F.gelu(F.linear(x, sd["fc.weight"], sd["fc.bias"]))
+    return F.linear(x, sd["fc2.weight"], sd["fc2.bias"])
+
+
+# --------------------------------------------------------------------------- VAE
+def vae_encoder_features(sd, x, taps=None):
+    """model/genconvit_vae.py:14-31,52-53 — 4x[Conv2d 3x3 s2 p1 -> BatchNorm2d(eval)
+    -> LeakyReLU(0.01)] then flatten (C-major)."""
+    for li, idx in enumerate((0, 3, 6, 9)):
+        x = F.conv2d(x, sd[f"encoder.features.{idx}.weight"], sd[f"encoder.features.{idx}.bias"],
+                     stride=2, padding=1)
+        b = f"encoder.features.{idx + 1}."
+        x = F.batch_norm(x, sd[b + "running_mean"], sd[b + "running_var"], sd[b + "weight"],
+                         sd[b + "bias"], training=False, eps=BN_EPS)
+        x = F.leaky_relu(x, LEAKY)
+        if taps is not None:
+            taps[f"vae_enc{li}"] = x
+    return torch.flatten(x, start_dim=1)
+
+
+def vae_encoder(sd, x, eps, as_written=False, want_kl=False, taps=None):
+    """Encoder.forward + reparameterize, model/genconvit_vae.py:43-60.
+
+    ``z = eps * exp(0.5*mu(x)) + mu(x)`` — the reference uses ``mu`` (not ``var``)
+    for the std (:45).  ``eps`` replaces ``torch.randn_like`` (:46).  With
+    ``as_written`` the three redundant ``mu`` GEMMs and the ``var`` GEMM are
+    executed like the reference does (CPU-baseline fidelity); results are equal."""
+    f = vae_encoder_features(sd, x, taps)
+    mu = F.linear(f, sd["encoder.mu.weight"], sd["encoder.mu.bias"])
+    kl = None
+    if as_written or want_kl:
+        var = F.linear(f, sd["encoder.var.weight"], sd["encoder.var.bias"])
+        kl = 0.5 * torch.mean(-0.5 * torch.sum(1 + var - mu ** 2 - var.exp(), dim=1), dim=0)  # :58
+    if as_written:
+        std = torch.exp(0.5 * F.linear(f, sd["encoder.mu.weight"], sd["encoder.mu.bias"]))
+        z = eps * std + F.linear(f, sd["encoder.mu.weight"], sd["encoder.mu.bias"])
+    else:
+        z = eps * torch.exp(0.5 * mu) + mu
+    if taps is not None:
+        taps["vae_mu"] = mu
+        taps["vae_z"] = z
+    return z, kl
+
+
+def vae_decoder(sd, z, taps=None):
+    """Decoder.forward, model/genconvit_vae.py:82-88 — Unflatten(256,7,7) then
+    4x[ConvTranspose2d 2x2 s2 -> LeakyReLU]."""
+    x = z.reshape(z.shape[0], 256, 7, 7)
+    for li, idx in enumerate((0, 2, 4, 6)):
+        x = F.leaky_relu(F.conv_transpose2d(x, sd[f"decoder.features.{idx}.weight"],
+                                            sd[f"decoder.features.{idx}.bias"], stride=2), LEAKY)
+        if taps is not None:
+            taps[f"vae_dec{li}"] = x
+    return x
+
+
+def resize224(x_hat):
+    """transforms.Resize((224,224), antialias=True) on a float tensor
+    (genconvit_vae.py:105,116) == bilinear, align_corners=False; antialias is a
+    no-op when upsampling."""
+    return F.interpolate(x_hat, size=(224, 224), mode="bilinear", align_corners=False, antialias=True)
+
+
+def vae_forward(sd, x, eps, as_written=False, want_kl=False, taps=None):
+    """GenConViTVAE.forward, model/genconvit_vae.py:107-116.  cat order is
+    [backbone(orig @224), backbone(x_hat @112)]; activation is ReLU (:104).
+    Returns (logits, resized reconstruction, kl or None)."""
+    z, kl = vae_encoder(sd, x, eps, as_written, want_kl, taps)
+    x_hat = vae_decoder(sd, z, taps)
+    x1 = convnext_tiny(sd, "convnext_backbone.", x)
+    x2 = convnext_tiny(sd, "convnext_backbone.", x_hat)
+    f = torch.cat((x1, x2), dim=1)
+    if taps is not None:
+        taps["vae_feat"] = f
+    f = F.relu(f)
+    f = F.relu(F.linear(f, sd["fc.weight"], sd["fc.bias"]))
+    logits = F.linear(f, sd["fc2.weight"], sd["fc2.bias"])
+    return logits, resize224(x_hat), kl
+
+
+def mse_per_frame(recons, images):
+    """Per-frame mean squared error; its mean over frames is the reference's
+    ``nn.MSELoss()(recons, images)`` (train/train_vae.py:24,76; train.py:57)."""
+    return ((recons - images) ** 2).flatten(1).mean(dim=1)
+
+
+# --------------------------------------------------------------------------- ensemble + vote
+def genconvit_forward(sd_ed, sd_vae, x, eps, net="genconvit", as_written=False):
+    """GenConViT.forward, model/genconvit.py:66-75: 'ed' -> (B,2); 'vae' -> (B,2);
+    anything else -> cat((ed, vae), dim=0) -> (2B,2)."""
+    if net == "ed":
+        return ed_forward(sd_ed, x)
+    if net == "vae":
+        return vae_forward(sd_vae, x, eps, as_written)[0]
+    x1 = ed_forward(sd_ed, x)
+    x2 = vae_forward(sd_vae, x, eps, as_written)[0]
+    return torch.cat((x1, x2), dim=0)
+
+
+def max_prediction_value(y_pred):
+    """model/pred_func.py:123-131."""
+    mean_val = torch.mean(y_pred, dim=0)
+    return (torch.argmax(mean_val).item(),
+            mean_val[0].item() if mean_val[0] > mean_val[1] else abs(1 - mean_val[1]).item())
+
+
+def vote(logits):
+    """pred_vid's tail, model/pred_func.py:120: sigmoid -> mean over rows -> argmax."""
+    return max_prediction_value(torch.sigmoid(logits.squeeze()))
+
+
+def preprocess_frame(frames_u8):
+    """model/pred_func.py:95-108 with dataset/loader.py:63-65,77: uint8 NHWC ->
+    float NCHW -> /255 -> Normalize(mean, std)."""
+    x = torch.as_tensor(frames_u8).float().permute(0, 3, 1, 2) / 255.0
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    return (x - mean) / std
+
+
+# --------------------------------------------------------------------------- Swin-T (A6)
+def _swin_rel_index(ws=7):
+    coords = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij"))
+    cf = coords.flatten(1)
+    rel = (cf[:, :, None] - cf[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1)                                   # (49,49)
+
+
+def _swin_attn_mask(H, W, ws, shift):
+    img = torch.zeros(1, H, W, 1)
+    cnt = 0
+    for h in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+        for w in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            img[:, h, w, :] = cnt
+            cnt += 1
+    mw = img.view(1, H // ws, ws, W // ws, ws, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws)
+    am = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0)   # (nW,49,49)
+
+
+def swin_block(sd, p, x, H, W, nh, shift, ws=7):
+    """timm 0.6.5 SwinTransformerBlock."""
+    B, L, C = x.shape
+    sc = x
+    y = F.layer_norm(x, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], LN_EPS_SWIN).view(B, H, W, C)
+    if shift:
+        y = torch.roll(y, shifts=(-shift, -shift), dims=(1, 2))
+    yw = y.view(B, H // ws, ws, W // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+    Bw, N = yw.shape[0], ws * ws
+    qkv = F.linear(yw, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]).reshape(Bw, N, 3, nh, C // nh)
+    q, k, v = qkv.permute(2, 0, 3, 1, 4).unbind(0)
+    attn = (q * (C // nh) ** -0.5) @ k.transpose(-2, -1)
+    bias = sd[p + "attn.relative_position_bias_table"][_swin_rel_index(ws).view(-1)].view(N, N, nh)
+    attn = attn + bias.permute(2, 0, 1).unsqueeze(0)
+    if shift:
+        m = _swin_attn_mask(H, W, ws, shift)
+        nW = m.shape[0]
+        attn = attn.view(Bw // nW, nW, nh, N, N) + m.unsqueeze(1).unsqueeze(0)
+        attn = attn.view(-1, nh, N, N)
+    attn = attn.softmax(dim=-1)
+    yw = (attn @ v).transpose(1, 2).reshape(Bw, N, C)
+    yw = F.linear(yw, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+    y = yw.view(B, H // ws, W // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, C)
+    if shift:
+        y = torch.roll(y, shifts=(shift, shift), dims=(1, 2))
+    x = sc + y.reshape(B, L, C)
+    y = F.layer_norm(x, (C,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], LN_EPS_SWIN)
+    y = F.linear(F.gelu(F.linear(y, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])),
+                 sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    return x + y
+
+
+def swin_tiny(sd, prefix, x):
+    """timm 0.6.5 ``swin_tiny_patch4_window7_224`` forward -> (N,1000).  The
+    reference only ever runs it once at construction (model/model_embedder.py:22)."""
+    p = prefix
+    x = F.conv2d(x, sd[p + "patch_embed.proj.weight"], sd[p + "patch_embed.proj.bias"], stride=4)
+    x = x.flatten(2).transpose(1, 2)
+    x = F.layer_norm(x, (96,), sd[p + "patch_embed.norm.weight"], sd[p + "patch_embed.norm.bias"], LN_EPS_SWIN)
+    H = W = 56
+    for i, (dim, depth, nh) in enumerate(zip(SWIN_DIMS, SWIN_DEPTHS, SWIN_HEADS)):
+        for j in range(depth):
+            shift = 0 if (j % 2 == 0 or H <= 7) else 3
+            x = swin_block(sd, p + f"layers.{i}.blocks.{j}.", x, H, W, nh, shift)
+        if i < 3:
+            B, L, C = x.shape
+            y = x.view(B, H, W, C)
+            y = torch.cat([y[:, 0::2, 0::2], y[:, 1::2, 0::2], y[:, 0::2, 1::2], y[:, 1::2, 1::2]], -1)
+            y = y.view(B, -1, 4 * C)
+            d = p + f"layers.{i}.downsample."
+            y = F.layer_norm(y, (4 * C,), sd[d + "norm.weight"], sd[d + "norm.bias"], LN_EPS_SWIN)
+            x = F.linear(y, sd[d + "reduction.weight"])
+            H, W = H // 2, W // 2
+    x = F.layer_norm(x, (768,), sd[p + "norm.weight"], sd[p + "norm.bias"], LN_EPS_SWIN)
+    x = x.mean(dim=1)
+    return F.linear(x, sd[p + "head.weight"], sd[p + "head.bias"])

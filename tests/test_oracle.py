@@ -1,0 +1,188 @@
+"""CPU tests of the oracle (oracle/cpu_ref.py): it must reproduce the committed golden
+vectors (made by the reference's own classes, tests/golden/make_golden.py) and agree with
+the independent Hugging Face implementation of ConvNeXt-T / Swin-T."""
+import numpy as np
+import pytest
+import torch
+
+from genconvit_amd import spec, synth
+from oracle import cpu_ref
+
+torch.set_grad_enabled(False)
+
+
+def slice64(t):
+    f = t.detach().flatten()
+    idx = torch.linspace(0, f.numel() - 1, 64).long()
+    return f[idx].numpy()
+
+
+def test_generator_matches_numpy_restatement():
+    key = synth._name_key(synth.DEFAULT_SEED, "probe")
+    a = synth._splitmix_bits24(key, 12345, 4096).numpy()
+    b = synth.splitmix_bits24_numpy(key, 12345, 4096)
+    assert np.array_equal(a, b)
+    u = synth.uniform01("probe", 1 << 16)
+    assert 0.0 <= float(u.min()) and float(u.max()) < 1.0
+    assert abs(float(u.mean()) - 0.5) < 0.01
+    n = synth.normal("probe", (1 << 16,))
+    assert abs(float(n.mean())) < 0.02 and abs(float(n.std()) - 1.0) < 0.02
+
+
+def test_generator_known_answers():
+    # frozen values: the generator must never drift (golden logits depend on it)
+    u = synth.uniform01("probe", 4)
+    assert u.dtype == torch.float32
+    assert [int(v * (1 << 24)) for v in u.tolist()] == \
+        synth.splitmix_bits24_numpy(synth._name_key(synth.DEFAULT_SEED, "probe"), 0, 4).tolist()
+    x = synth.make_frames(1)
+    assert x.shape == (1, 3, 224, 224)
+    assert -2.2 < float(x.min()) < -2.0 and 2.5 < float(x.max()) < 2.7
+
+
+def test_param_counts():
+    n_cnx = sum(int(np.prod(s)) for _, s, _ in spec.convnext_tiny_spec(""))
+    assert n_cnx == 28_589_128                      # published convnext_tiny count
+    n_swin = sum(int(np.prod(s)) for _, s, _ in spec.swin_tiny_spec(""))
+    assert n_swin == 28_288_354                     # published swin_tiny count
+    ed_ae = sum(int(np.prod(s)) for n, s, _ in spec.ed_spec() if n.startswith(("encoder.", "decoder.")))
+    assert ed_ae == 567_123
+    vae_enc = sum(int(np.prod(s)) for n, s, k in spec.vae_spec() if n.startswith("encoder.")
+                  and k not in ("bn_mean", "bn_var"))
+    assert vae_enc == 635_986_432
+    vae_dec = sum(int(np.prod(s)) for n, s, _ in spec.vae_spec() if n.startswith("decoder."))
+    assert vae_dec == 76_083
+
+
+def test_ed_matches_reference_golden(golden, sd_ed):
+    x = synth.make_frames(4)
+    taps = {}
+    logits = cpu_ref.ed_forward(sd_ed, x, taps)
+    assert np.allclose(logits.numpy(), golden["ed_logits"], rtol=0, atol=2e-6)
+    assert np.allclose(slice64(taps["ed_feat"]), golden["ed_feat_slice"], rtol=0, atol=2e-5)
+    enc = cpu_ref.ed_encoder(sd_ed, x[:2])
+    assert np.allclose(slice64(enc), golden["ed_enc_slice"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(slice64(cpu_ref.ed_decoder(sd_ed, enc)), golden["ed_dec_slice"], rtol=1e-6, atol=1e-6)
+
+
+def test_vae_matches_reference_golden(golden, sd_vae):
+    x = synth.make_frames(4)
+    eps = torch.from_numpy(golden["vae_eps"])
+    logits, recon, kl = cpu_ref.vae_forward(sd_vae, x, eps, want_kl=True)
+    assert np.allclose(logits.numpy(), golden["vae_logits"], rtol=0, atol=2e-6)
+    assert np.allclose(slice64(recon), golden["vae_recon_slice"], rtol=1e-6, atol=1e-6)
+    assert abs(float(kl) - float(golden["vae_kl"])) <= 1e-5 * abs(float(golden["vae_kl"]))
+    assert np.allclose(cpu_ref.mse_per_frame(recon, x).numpy(), golden["vae_mse"], rtol=1e-6)
+    # the reference's redundant 3x mu + var evaluation gives the same z
+    z_a, _ = cpu_ref.vae_encoder(sd_vae, x[:1], eps[:1], as_written=True)
+    z_b, _ = cpu_ref.vae_encoder(sd_vae, x[:1], eps[:1], as_written=False)
+    assert torch.equal(z_a, z_b)
+
+
+def test_vote_matches_reference_golden(golden):
+    logits = torch.from_numpy(golden["genconvit_logits"])
+    y, val = cpu_ref.vote(logits)
+    assert y == int(golden["vote_idx"])
+    assert abs(val - float(golden["vote_val"])) < 1e-7
+    assert {0: "REAL", 1: "FAKE"}[y ^ 1] == str(golden["vote_label"])
+
+
+def test_hybrid_embed_probe_dims(golden):
+    # model/model_embedder.py:16-37 with a (1,1000)-logit embedder: grid (1,1000), proj 1000->768
+    assert golden["hybrid_grid"].tolist() == [1, 1000]
+    assert golden["hybrid_proj_shape"].tolist() == [768, 1000, 1, 1]
+
+
+def _hf_convnext(sd):
+    from transformers import ConvNextConfig, ConvNextForImageClassification
+    m = ConvNextForImageClassification(ConvNextConfig(num_labels=1000, layer_norm_eps=1e-6)).eval()
+    new = {}
+    new["convnext.embeddings.patch_embeddings.weight"] = sd["stem.0.weight"]
+    new["convnext.embeddings.patch_embeddings.bias"] = sd["stem.0.bias"]
+    new["convnext.embeddings.layernorm.weight"] = sd["stem.1.weight"]
+    new["convnext.embeddings.layernorm.bias"] = sd["stem.1.bias"]
+    for i, depth in enumerate(spec.CONVNEXT_DEPTHS):
+        if i > 0:
+            for a in (0, 1):
+                for wb in ("weight", "bias"):
+                    new[f"convnext.encoder.stages.{i}.downsampling_layer.{a}.{wb}"] = \
+                        sd[f"stages.{i}.downsample.{a}.{wb}"]
+        for j in range(depth):
+            s, d = f"stages.{i}.blocks.{j}.", f"convnext.encoder.stages.{i}.layers.{j}."
+            new[d + "layer_scale_parameter"] = sd[s + "gamma"]
+            for a, b in (("conv_dw", "dwconv"), ("norm", "layernorm"), ("mlp.fc1", "pwconv1"), ("mlp.fc2", "pwconv2")):
+                for wb in ("weight", "bias"):
+                    new[d + f"{b}.{wb}"] = sd[s + f"{a}.{wb}"]
+    new["convnext.layernorm.weight"] = sd["head.norm.weight"]
+    new["convnext.layernorm.bias"] = sd["head.norm.bias"]
+    new["classifier.weight"] = sd["head.fc.weight"]
+    new["classifier.bias"] = sd["head.fc.bias"]
+    m.load_state_dict(new, strict=True)
+    return m
+
+
+@pytest.mark.parametrize("res", [224, 112])
+def test_convnext_restatement_vs_huggingface(res):
+    """ConvNeXt-T lives in absent timm==0.6.5 (parity unpinned by the reference); the
+    restatement is cross-checked against an independent implementation of the same
+    published architecture, at both resolutions the path uses (224 and the VAE's 112)."""
+    sd = synth.make_state_dict(spec.convnext_tiny_spec(""), tag="hfcheck/")
+    m = _hf_convnext(sd)
+    x = synth.make_frames(2)
+    if res != 224:
+        x = torch.nn.functional.avg_pool2d(x, 2)
+    ours = cpu_ref.convnext_tiny(sd, "", x)
+    theirs = m(pixel_values=x).logits
+    assert float((ours - theirs).abs().max()) < 2e-5
+    assert float(ours.abs().max()) > 0.5           # non-degenerate
+
+
+def _hf_swin(sd):
+    from transformers import SwinConfig, SwinForImageClassification
+    m = SwinForImageClassification(SwinConfig(num_labels=1000)).eval()
+    hs = m.state_dict()
+    new = {}
+    new["swin.embeddings.patch_embeddings.projection.weight"] = sd["patch_embed.proj.weight"]
+    new["swin.embeddings.patch_embeddings.projection.bias"] = sd["patch_embed.proj.bias"]
+    new["swin.embeddings.norm.weight"] = sd["patch_embed.norm.weight"]
+    new["swin.embeddings.norm.bias"] = sd["patch_embed.norm.bias"]
+    for i, (dim, depth) in enumerate(zip(spec.SWIN_DIMS, spec.SWIN_DEPTHS)):
+        for j in range(depth):
+            s, d = f"layers.{i}.blocks.{j}.", f"swin.encoder.layers.{i}.blocks.{j}."
+            qkv_w, qkv_b = sd[s + "attn.qkv.weight"], sd[s + "attn.qkv.bias"]
+            for n, nm in enumerate(("q_proj", "k_proj", "v_proj")):
+                new[d + f"attention.{nm}.weight"] = qkv_w[n * dim:(n + 1) * dim]
+                new[d + f"attention.{nm}.bias"] = qkv_b[n * dim:(n + 1) * dim]
+            new[d + "attention.o_proj.weight"] = sd[s + "attn.proj.weight"]
+            new[d + "attention.o_proj.bias"] = sd[s + "attn.proj.bias"]
+            new[d + "attention.relative_position_bias.relative_position_bias_table"] = \
+                sd[s + "attn.relative_position_bias_table"]
+            for a, b in (("norm1", "layernorm_before"), ("norm2", "layernorm_after"),
+                         ("mlp.fc1", "mlp.fc1"), ("mlp.fc2", "mlp.fc2")):
+                for wb in ("weight", "bias"):
+                    new[d + f"{b}.{wb}"] = sd[s + f"{a}.{wb}"]
+        if i < 3:
+            s, d = f"layers.{i}.downsample.", f"swin.encoder.layers.{i}.downsample."
+            new[d + "reduction.weight"] = sd[s + "reduction.weight"]
+            new[d + "norm.weight"] = sd[s + "norm.weight"]
+            new[d + "norm.bias"] = sd[s + "norm.bias"]
+    new["swin.layernorm.weight"] = sd["norm.weight"]
+    new["swin.layernorm.bias"] = sd["norm.bias"]
+    new["classifier.weight"] = sd["head.weight"]
+    new["classifier.bias"] = sd["head.bias"]
+    extra = {k: v for k, v in hs.items() if k not in new}      # index buffers, if registered
+    missing = [k for k in extra if "relative_position_index" not in k and "mask" not in k]
+    assert not missing, missing
+    new.update(extra)
+    m.load_state_dict(new, strict=True)
+    return m
+
+
+def test_swin_restatement_vs_huggingface():
+    sd = synth.make_state_dict(spec.swin_tiny_spec(""), tag="hfcheck/")
+    m = _hf_swin(sd)
+    x = synth.make_frames(2)
+    ours = cpu_ref.swin_tiny(sd, "", x)
+    theirs = m(pixel_values=x).logits
+    assert float((ours - theirs).abs().max()) < 5e-5
+    assert float(ours.abs().max()) > 0.5
