@@ -1,0 +1,275 @@
+"""ctypes binding of ``libgenconvit_hip.so`` (C ABI: include/genconvit_hip.h).
+
+The north-star asks for cffi; cffi is not installed in this image, ctypes (stdlib) binds the same
+C ABI.  There is NO CPU fallback: if the library is missing, or there is no gfx950 device, the
+calls raise.
+
+The library is linked without a hard dependency on a particular HIP runtime (``-no-hip-rt``):
+PyTorch-ROCm wheels bundle their own ``libamdhip64.so`` and a second runtime instance in the same
+process would not understand torch's streams.  So the runtime already used by the process is made
+globally visible first (torch's bundled copy when torch is importable, /opt/rocm's otherwise).
+"""
+from __future__ import annotations
+
+import ctypes
+import ctypes.util
+import json
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgenconvit_hip.so")
+
+GCV_F32, GCV_BF16, GCV_F16 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_LEAKY = 0, 1, 2, 3
+A_PLAIN, A_IM2COL3_POOL, A_IM2COL3_S2 = 0, 1, 2
+EPI_BIAS_ACT, EPI_RESID, EPI_POOL4, EPI_CONVT, EPI_SPLITK = 0, 1, 2, 3, 4
+
+c_void_p, c_int, c_int64, c_float, c_char_p, c_size_t = (ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                                         ctypes.c_float, ctypes.c_char_p, ctypes.c_size_t)
+
+
+class TensorDesc(ctypes.Structure):
+    _fields_ = [("name", c_char_p), ("data", c_void_p), ("numel", c_int64), ("on_device", c_int)]
+
+
+class GemmArgs(ctypes.Structure):
+    _fields_ = [("A", c_void_p), ("Wt", c_void_p), ("C", c_void_p), ("bias", c_void_p), ("gamma", c_void_p),
+                ("resid", c_void_p), ("partial", c_void_p)] + \
+               [(n, c_int) for n in ("M", "N", "K", "lda", "ldc", "act", "splitk", "k_per_split", "H", "W",
+                                     "cin_log2", "cout_log2")]
+
+
+# every symbol include/genconvit_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "gcv_last_error": (c_char_p, []),
+    "gcv_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_int]),
+    "gcv_destroy": (None, [c_void_p]),
+    "gcv_workspace_bytes": (c_size_t, [c_void_p]),
+    "gcv_load_ed": (c_int, [c_void_p, ctypes.POINTER(TensorDesc), c_int]),
+    "gcv_load_vae": (c_int, [c_void_p, ctypes.POINTER(TensorDesc), c_int]),
+    "gcv_load_swin": (c_int, [c_void_p, ctypes.POINTER(TensorDesc), c_int, c_char_p]),
+    "gcv_ed_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "gcv_vae_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gcv_convnext_forward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "gcv_swin_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "gcv_vote": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "gcv_profile_enable": (c_int, [c_void_p, c_int]),
+    "gcv_profile_report": (c_char_p, [c_void_p]),
+    "gcv_k_gemm": (c_int, [c_int, c_int, c_int, ctypes.POINTER(GemmArgs), c_void_p]),
+    "gcv_k_stem_ln": (c_int, [c_int, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "gcv_k_dwconv7_ln": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                 c_int, c_int, c_float, c_void_p]),
+    "gcv_k_ln_patchify": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                  c_void_p]),
+    "gcv_k_layernorm_rows": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "gcv_k_pool_ln": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "gcv_k_conv3_first": (c_int, [c_int, c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                  c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "gcv_k_convt2_small": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "gcv_k_reparam": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "gcv_k_head_tail": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "gcv_k_resize_mse": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class GenConViTHipError(RuntimeError):
+    pass
+
+
+def _preload_hip_runtime():
+    cands = []
+    try:
+        import torch
+        cands.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except Exception:   # torch not importable: plain C-ABI use
+        pass
+    cands += ["/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"]
+    last = None
+    for c in cands:
+        if os.path.isabs(c) and not os.path.exists(c):
+            continue
+        try:
+            return ctypes.CDLL(c, mode=ctypes.RTLD_GLOBAL)
+        except OSError as e:   # try the next candidate
+            last = e
+    raise GenConViTHipError(f"cannot load a HIP runtime (libamdhip64.so): {last}")
+
+
+def load():
+    """Load (once) and return the ctypes library with all signatures set.  Raises if absent."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise GenConViTHipError(
+                f"{LIB_PATH} not found — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C genconvit_amd/csrc`). There is no CPU fallback.")
+        _preload_hip_runtime()
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)    # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def last_error() -> str:
+    return (load().gcv_last_error() or b"").decode(errors="replace")
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise GenConViTHipError(f"{what} failed (rc={rc}): {last_error()}")
+
+
+def dtype_code(torch_dtype) -> int:
+    import torch
+    try:
+        return {torch.float32: GCV_F32, torch.bfloat16: GCV_BF16, torch.float16: GCV_F16}[torch_dtype]
+    except KeyError:
+        raise GenConViTHipError(f"unsupported dtype {torch_dtype}; use float32, bfloat16 or float16") from None
+
+
+def current_stream_ptr(device) -> int:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class Handle:
+    """Owns one ``gcv_handle`` (packed weights + workspace) on one device / dtype."""
+
+    def __init__(self, device_index: int, torch_dtype, max_batch: int):
+        import torch
+        self.lib = load()
+        if not torch.cuda.is_available():
+            raise GenConViTHipError("no HIP device visible: the GenConViT HIP path needs an MI355X (gfx950); "
+                                    "there is no CPU fallback")
+        self.device_index = int(device_index)
+        self.dtype = torch_dtype
+        self.max_batch = int(max_batch)
+        self._h = c_void_p()
+        check(self.lib.gcv_create(ctypes.byref(self._h), self.device_index, dtype_code(torch_dtype), self.max_batch),
+              "gcv_create")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.gcv_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # interpreter shutdown
+            pass
+
+    # -- weights ---------------------------------------------------------------------------
+    @staticmethod
+    def _descs(state_dict, skip_prefixes=()):
+        import torch
+        keep = []
+        names = []
+        for k, v in state_dict.items():
+            if not torch.is_tensor(v) or not v.is_floating_point() or any(k.startswith(p) or p in k for p in skip_prefixes):
+                continue
+            t = v.detach()
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.float().contiguous()
+            keep.append(t)
+            names.append(k.encode())
+        arr = (TensorDesc * len(keep))()
+        for i, (n, t) in enumerate(zip(names, keep)):
+            arr[i] = TensorDesc(n, t.data_ptr(), t.numel(), 1 if t.is_cuda else 0)
+        return arr, keep, names
+
+    _OFF_PATH = ("embedder.", "patch_embed.", "encoder.fc1.", "encoder.fc2.", "fc3.", "num_batches_tracked")
+
+    def load_ed(self, state_dict):
+        arr, keep, _ = self._descs(state_dict, self._OFF_PATH)
+        check(self.lib.gcv_load_ed(self._h, arr, len(keep)), "gcv_load_ed")
+
+    def load_vae(self, state_dict):
+        arr, keep, _ = self._descs(state_dict, self._OFF_PATH)
+        check(self.lib.gcv_load_vae(self._h, arr, len(keep)), "gcv_load_vae")
+
+    def load_swin(self, state_dict, prefix=""):
+        arr, keep, _ = self._descs(state_dict)
+        check(self.lib.gcv_load_swin(self._h, arr, len(keep), prefix.encode()), "gcv_load_swin")
+
+    # -- forwards --------------------------------------------------------------------------
+    def _check_x(self, x, res=224):
+        import torch
+        if not (torch.is_tensor(x) and x.is_cuda and x.device.index == self.device_index):
+            raise GenConViTHipError(f"input must be a CUDA(HIP) tensor on device {self.device_index}")
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != res or x.shape[3] != res:
+            raise GenConViTHipError(f"input must be (B,3,{res},{res}), got {tuple(x.shape)}")
+        if x.dtype != self.dtype:
+            raise GenConViTHipError(f"input dtype {x.dtype} != handle dtype {self.dtype}")
+        if x.shape[0] < 1 or x.shape[0] > self.max_batch:
+            raise GenConViTHipError(f"batch {x.shape[0]} outside [1,{self.max_batch}]")
+        return x.contiguous()
+
+    def ed_forward(self, x):
+        import torch
+        x = self._check_x(x)
+        out = torch.empty((x.shape[0], 2), dtype=torch.float32, device=x.device)
+        check(self.lib.gcv_ed_forward(self._h, x.data_ptr(), x.shape[0], out.data_ptr(), current_stream_ptr(x.device)),
+              "gcv_ed_forward")
+        return out
+
+    def vae_forward(self, x, eps, want_recon=True, want_mse=False, want_kl=False):
+        import torch
+        x = self._check_x(x)
+        B = x.shape[0]
+        if not (torch.is_tensor(eps) and eps.is_cuda and tuple(eps.shape) == (B, 12544)):
+            raise GenConViTHipError(f"eps must be a device tensor of shape ({B},12544)")
+        eps = eps.float().contiguous()
+        out = torch.empty((B, 2), dtype=torch.float32, device=x.device)
+        recon = torch.empty((B, 3, 224, 224), dtype=self.dtype, device=x.device) if want_recon else None
+        mse = torch.empty((B,), dtype=torch.float32, device=x.device) if want_mse else None
+        kl = torch.empty((1,), dtype=torch.float32, device=x.device) if want_kl else None
+        p = lambda t: t.data_ptr() if t is not None else None
+        check(self.lib.gcv_vae_forward(self._h, x.data_ptr(), eps.data_ptr(), B, out.data_ptr(), p(recon), p(mse), p(kl),
+                                       current_stream_ptr(x.device)), "gcv_vae_forward")
+        return out, recon, mse, kl
+
+    def convnext_forward(self, which, x):
+        import torch
+        x = self._check_x(x, res=x.shape[-1])
+        out = torch.empty((x.shape[0], 1000), dtype=self.dtype, device=x.device)
+        check(self.lib.gcv_convnext_forward(self._h, which, x.data_ptr(), x.shape[0], x.shape[-1], out.data_ptr(),
+                                            current_stream_ptr(x.device)), "gcv_convnext_forward")
+        return out
+
+    def swin_forward(self, x):
+        import torch
+        x = self._check_x(x)
+        out = torch.empty((x.shape[0], 1000), dtype=self.dtype, device=x.device)
+        check(self.lib.gcv_swin_forward(self._h, x.data_ptr(), x.shape[0], out.data_ptr(), current_stream_ptr(x.device)),
+              "gcv_swin_forward")
+        return out
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.gcv_workspace_bytes(self._h))
+
+    def profile_enable(self, on=True):
+        check(self.lib.gcv_profile_enable(self._h, 1 if on else 0), "gcv_profile_enable")
+
+    def profile_report(self):
+        return json.loads((self.lib.gcv_profile_report(self._h) or b"[]").decode())
+
+
+def vote(logits):
+    """Device-side ``mean(sigmoid(logits), dim=0)`` (model/pred_func.py:120,125) -> (2,) fp32 tensor."""
+    import torch
+    lib = load()
+    logits = logits.float().contiguous().reshape(-1, 2)
+    out = torch.empty((2,), dtype=torch.float32, device=logits.device)
+    check(lib.gcv_vote(logits.data_ptr(), logits.shape[0], out.data_ptr(), current_stream_ptr(logits.device)), "gcv_vote")
+    return out

@@ -1,0 +1,244 @@
+// C ABI of libgenconvit_hip.so — see include/genconvit_hip.h for the contract.
+#include "../../include/genconvit_hip.h"
+
+#include <cstdio>
+#include <map>
+#include <sstream>
+
+#include "gemm.h"
+#include "kernels.h"
+#include "net.h"
+
+namespace gcv {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+const char* get_error() { return g_err.c_str(); }
+
+hipEvent_t Profiler::get_event() {
+  if (next_event == pool.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    pool.push_back(e);
+  }
+  return pool[next_event++];
+}
+Profiler::~Profiler() {
+  for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+}
+}  // namespace gcv
+
+using namespace gcv;
+
+struct gcv_handle {
+  NetBase* net;
+  std::string report;
+};
+
+static int to_map(const gcv_tensor_desc* w, int n, TensorMap& m) {
+  GCV_REQUIRE(w != nullptr && n > 0, "empty tensor list");
+  for (int i = 0; i < n; ++i) {
+    GCV_REQUIRE(w[i].name && w[i].data && w[i].numel > 0, "tensor descriptor with null name/data");
+    m[w[i].name] = TensorRef{(const float*)w[i].data, w[i].numel, w[i].on_device != 0};
+  }
+  return 0;
+}
+
+extern "C" {
+
+const char* gcv_last_error(void) { return get_error(); }
+
+int gcv_create(gcv_handle** out, int device, int dtype, int max_batch) {
+  GCV_REQUIRE(out != nullptr, "null handle pointer");
+  *out = nullptr;
+  GCV_REQUIRE(max_batch >= 1 && max_batch <= 512, "max_batch must be in [1,512]");
+  int ndev = 0;
+  GCV_CHECK_HIP(hipGetDeviceCount(&ndev));
+  GCV_REQUIRE(device >= 0 && device < ndev, "no such HIP device");
+  hipDeviceProp_t prop;
+  GCV_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+  GCV_REQUIRE(std::string(prop.gcnArchName).rfind("gfx950", 0) == 0,
+              std::string("kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+  NetBase* net = nullptr;
+  switch (dtype) {
+    case GCV_F32:  net = make_net_f32(); break;
+    case GCV_BF16: net = make_net_bf16(); break;
+    case GCV_F16:  net = make_net_f16(); break;
+    default: set_error("dtype must be GCV_F32, GCV_BF16 or GCV_F16"); return -2;
+  }
+  net->device = device;
+  net->dtype = dtype;
+  net->max_batch = max_batch;
+  const int rc = net->init();
+  if (rc) { delete net; return rc; }
+  *out = new gcv_handle{net, {}};
+  return 0;
+}
+
+void gcv_destroy(gcv_handle* h) {
+  if (!h) return;
+  delete h->net;
+  delete h;
+}
+
+int gcv_load_ed(gcv_handle* h, const gcv_tensor_desc* w, int n) {
+  GCV_REQUIRE(h, "null handle");
+  TensorMap m;
+  if (int rc = to_map(w, n, m)) return rc;
+  return h->net->load_ed(m);
+}
+
+int gcv_load_vae(gcv_handle* h, const gcv_tensor_desc* w, int n) {
+  GCV_REQUIRE(h, "null handle");
+  TensorMap m;
+  if (int rc = to_map(w, n, m)) return rc;
+  return h->net->load_vae(m);
+}
+
+int gcv_load_swin(gcv_handle* h, const gcv_tensor_desc* w, int n, const char* prefix) {
+  GCV_REQUIRE(h, "null handle");
+  TensorMap m;
+  if (int rc = to_map(w, n, m)) return rc;
+  return h->net->load_swin(m, prefix ? prefix : "");
+}
+
+int gcv_ed_forward(gcv_handle* h, const void* x_nchw, int batch, float* logits, gcv_stream stream) {
+  GCV_REQUIRE(h, "null handle");
+  GCV_CHECK_HIP(hipSetDevice(h->net->device));
+  return h->net->ed_forward(x_nchw, batch, logits, (hipStream_t)stream);
+}
+
+int gcv_vae_forward(gcv_handle* h, const void* x_nchw, const float* eps, int batch, float* logits, void* recon224,
+                    float* mse, float* kl, gcv_stream stream) {
+  GCV_REQUIRE(h, "null handle");
+  GCV_CHECK_HIP(hipSetDevice(h->net->device));
+  return h->net->vae_forward(x_nchw, eps, batch, logits, recon224, mse, kl, (hipStream_t)stream);
+}
+
+int gcv_convnext_forward(gcv_handle* h, int which, const void* x_nchw, int batch, int res, void* logits1000,
+                         gcv_stream stream) {
+  GCV_REQUIRE(h, "null handle");
+  GCV_CHECK_HIP(hipSetDevice(h->net->device));
+  return h->net->convnext_forward(which, x_nchw, batch, res, logits1000, (hipStream_t)stream);
+}
+
+int gcv_swin_forward(gcv_handle* h, const void* x_nchw, int batch, void* logits1000, gcv_stream stream) {
+  GCV_REQUIRE(h, "null handle");
+  GCV_CHECK_HIP(hipSetDevice(h->net->device));
+  return h->net->swin_forward(x_nchw, batch, logits1000, (hipStream_t)stream);
+}
+
+int gcv_vote(const float* logits, int rows, float* mean2, gcv_stream stream) {
+  GCV_REQUIRE(logits && mean2 && rows > 0, "vote: bad arguments");
+  return launch_vote(logits, rows, mean2, (hipStream_t)stream);
+}
+
+size_t gcv_workspace_bytes(const gcv_handle* h) { return h ? h->net->workspace_bytes() : 0; }
+
+int gcv_profile_enable(gcv_handle* h, int on) {
+  GCV_REQUIRE(h, "null handle");
+  h->net->prof.enabled = on != 0;
+  h->net->prof.reset();
+  return 0;
+}
+
+// JSON: [{"tag":..., "launches":n, "ms":total, "flops":total, "bytes":total}, ...] aggregated by tag.
+const char* gcv_profile_report(gcv_handle* h) {
+  if (!h) return "[]";
+  Profiler& p = h->net->prof;
+  struct Agg { int n = 0; double ms = 0, flops = 0, bytes = 0; };
+  std::map<std::string, Agg> agg;
+  std::vector<std::string> order;
+  for (auto& r : p.recs) {
+    float ms = 0.0f;
+    if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) ms = -1.0f;
+    if (!agg.count(r.tag)) order.push_back(r.tag);
+    Agg& a = agg[r.tag];
+    a.n += 1; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+  }
+  std::ostringstream os;
+  os.precision(9);
+  os << "[";
+  for (size_t i = 0; i < order.size(); ++i) {
+    const Agg& a = agg[order[i]];
+    os << (i ? "," : "") << "{\"tag\":\"" << order[i] << "\",\"launches\":" << a.n << ",\"ms\":" << a.ms
+       << ",\"flops\":" << a.flops << ",\"bytes\":" << a.bytes << "}";
+  }
+  os << "]";
+  h->report = os.str();
+  p.reset();
+  return h->report.c_str();
+}
+
+// ------------------------------------------------------------------ per-kernel entry points (unit parity)
+#define DISPATCH_DT(dt, CALL)                                    \
+  switch (dt) {                                                  \
+    case GCV_F32:  { typedef float T;  return CALL; }            \
+    case GCV_BF16: { typedef bf16_t T; return CALL; }            \
+    case GCV_F16:  { typedef half_t T; return CALL; }            \
+    default: set_error("bad dtype"); return -2;                  \
+  }
+
+int gcv_k_gemm(int dtype, int a_mode, int epi, const gcv_gemm_args* a, gcv_stream stream) {
+  GCV_REQUIRE(a, "null args");
+  GemmArgs g{};
+  g.A = a->A; g.Wt = a->Wt; g.C = a->C; g.bias = a->bias; g.gamma = a->gamma; g.resid = a->resid;
+  g.partial = a->partial; g.M = a->M; g.N = a->N; g.K = a->K; g.lda = a->lda; g.ldc = a->ldc; g.act = a->act;
+  g.splitk = a->splitk; g.k_per_split = a->k_per_split; g.H = a->H; g.W = a->W; g.cin_log2 = a->cin_log2;
+  g.cout_log2 = a->cout_log2;
+  DISPATCH_DT(dtype, launch_gemm<T>(g, a_mode, epi, (hipStream_t)stream));
+}
+
+int gcv_k_stem_ln(int dtype, const void* x, int64_t sb, int64_t sc, int64_t sy, int64_t sx, const float* wp,
+                  const float* bias, const float* lnw, const float* lnb, void* out, int nimg, int Ho, int Wo,
+                  float eps, gcv_stream s) {
+  DISPATCH_DT(dtype, launch_stem_ln<T>((const T*)x, sb, sc, sy, sx, wp, bias, lnw, lnb, (T*)out, nimg, Ho, Wo, eps,
+                                       (hipStream_t)s));
+}
+
+int gcv_k_dwconv7_ln(int dtype, const void* x, const float* wdw, const float* bdw, const float* lnw,
+                     const float* lnb, void* y, int nimg, int H, int W, int C, float eps, gcv_stream s) {
+  DISPATCH_DT(dtype, launch_dwconv7_ln<T>((const T*)x, wdw, bdw, lnw, lnb, (T*)y, nimg, H, W, C, eps, (hipStream_t)s));
+}
+
+int gcv_k_ln_patchify(int dtype, const void* x, const float* w, const float* b, void* out, int nimg, int H, int W,
+                      int C, float eps, gcv_stream s) {
+  DISPATCH_DT(dtype, launch_ln_patchify<T>((const T*)x, w, b, (T*)out, nimg, H, W, C, eps, (hipStream_t)s));
+}
+
+int gcv_k_layernorm_rows(int dtype, const void* x, const float* w, const float* b, void* out, int64_t rows, int C,
+                         float eps, gcv_stream s) {
+  DISPATCH_DT(dtype, launch_layernorm_rows<T>((const T*)x, w, b, (T*)out, rows, C, eps, (hipStream_t)s));
+}
+
+int gcv_k_pool_ln(int dtype, const void* x, const float* w, const float* b, void* out, int nimg, int HW, int C,
+                  float eps, gcv_stream s) {
+  DISPATCH_DT(dtype, launch_pool_ln<T>((const T*)x, w, b, (T*)out, nimg, HW, C, eps, (hipStream_t)s));
+}
+
+int gcv_k_conv3_first(int dtype, const void* x, int64_t sb, int64_t sc, int64_t sy, int64_t sx, const float* wp,
+                      const float* bias, void* out, int nimg, int H, int W, int pool, int act, gcv_stream s) {
+  DISPATCH_DT(dtype, launch_conv3_first<T>((const T*)x, sb, sc, sy, sx, wp, bias, (T*)out, nimg, H, W, pool != 0, act,
+                                           (hipStream_t)s));
+}
+
+int gcv_k_convt2_small(int dtype, const void* x, const float* wp, const float* bias, void* out, int nimg, int H,
+                       int W, int act, gcv_stream s) {
+  DISPATCH_DT(dtype, launch_convt2_small<T>((const T*)x, wp, bias, (T*)out, nimg, H, W, act, (hipStream_t)s));
+}
+
+int gcv_k_reparam(int dtype, const float* partial, int splitk, const float* bias, const float* eps, float* mu_out,
+                  void* z_nhwc, int B, int N, gcv_stream s) {
+  DISPATCH_DT(dtype, launch_reparam<T>(partial, splitk, bias, eps, mu_out, (T*)z_nhwc, B, N, (hipStream_t)s));
+}
+
+int gcv_k_head_tail(int dtype, const void* h, const float* w, const float* bias, float* logits, int B, int K,
+                    gcv_stream s) {
+  DISPATCH_DT(dtype, launch_head_tail<T>((const T*)h, w, bias, logits, B, K, (hipStream_t)s));
+}
+
+int gcv_k_resize_mse(int dtype, const void* xhat, const void* img, void* recon, float* msepart, float* mse, int B,
+                     gcv_stream s) {
+  DISPATCH_DT(dtype, launch_resize_mse<T>((const T*)xhat, (const T*)img, (T*)recon, msepart, mse, B, (hipStream_t)s));
+}
+
+}  // extern "C"

@@ -1,0 +1,46 @@
+// Non-GEMM kernels of the GenConViT path: HBM-bound NHWC kernels with
+// fp32 math, 64-lane wave reductions and LDS-staged cross-channel statistics.
+//   K3  stem conv4x4s4 + LayerNorm2d            stem_ln_kernel
+//   K4  depthwise 7x7 + LayerNorm               dwconv7_ln_kernel
+//   K6  LayerNorm2d + 2x2 space-to-depth        ln_patchify_kernel   (conv2x2s2 itself is a GEMM)
+//   K7  global-avg-pool + LayerNorm2d           pool_ln_kernel       (fc is a GEMM)
+//   K1/K9 first 3->16 conv (Cin=3 is not MFMA-shaped)   conv3_first_kernel
+//   K2/K12 last 16->3 ConvTranspose2d           convt2_small_kernel
+//   K10/K11 split-K reduce + bias + reparameterise      reparam_kernel, kl_rows_kernel
+//   K8  500->2 head tail                        head_tail_kernel
+//   K13/K14 bilinear 112->224 (+ per-frame MSE) resize_mse_kernel
+//   K15 sigmoid -> mean over rows               vote_kernel
+#pragma once
+#include "common.h"
+
+namespace gcv {
+
+// ------------------------------------------------------------------ launch wrappers (defined in kernels_impl.h)
+template <typename T> int launch_stem_ln(const T* x, int64_t sb, int64_t sc, int64_t sy, int64_t sx, const float* wp,
+                                         const float* bias, const float* lnw, const float* lnb, T* out, int nimg,
+                                         int Ho, int Wo, float eps, hipStream_t s);
+template <typename T> int launch_dwconv7_ln(const T* x, const float* wdw, const float* bdw, const float* lnw,
+                                            const float* lnb, T* y, int nimg, int H, int W, int C, float eps,
+                                            hipStream_t s);
+template <typename T> int launch_ln_patchify(const T* x, const float* w, const float* b, T* out, int nimg, int H,
+                                             int W, int C, float eps, hipStream_t s);
+template <typename T> int launch_layernorm_rows(const T* x, const float* w, const float* b, T* out, int64_t rows,
+                                                int C, float eps, hipStream_t s);
+template <typename T> int launch_pool_ln(const T* x, const float* w, const float* b, T* out, int nimg, int HW, int C,
+                                         float eps, hipStream_t s);
+template <typename T> int launch_conv3_first(const T* x, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
+                                             const float* wp, const float* bias, T* out, int nimg, int H, int W,
+                                             bool pool, int act, hipStream_t s);
+template <typename T> int launch_convt2_small(const T* x, const float* wp, const float* bias, T* out, int nimg, int H,
+                                              int W, int act, hipStream_t s);
+template <typename T> int launch_reparam(const float* partial, int splitk, const float* bias, const float* eps,
+                                         float* mu_out, T* z_nhwc, int B, int N, hipStream_t s);
+template <typename T> int launch_head_tail(const T* h, const float* w, const float* bias, float* logits, int B, int K,
+                                           hipStream_t s);
+template <typename T> int launch_resize_mse(const T* xhat, const T* img, T* recon, float* msepart, float* mse, int B,
+                                            hipStream_t s);
+int launch_kl(const float* partial, int splitk, const float* bias, const float* mu, float* rowsum, float* kl, int B,
+              int N, hipStream_t s);
+int launch_vote(const float* logits, int rows, float* mean2, hipStream_t s);
+
+}  // namespace gcv

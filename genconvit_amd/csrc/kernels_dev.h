@@ -1,0 +1,552 @@
+// Non-GEMM kernels of the GenConViT path: HBM-bound NHWC kernels with
+// fp32 math, 64-lane wave reductions and LDS-staged cross-channel statistics.
+//   K3  stem conv4x4s4 + LayerNorm2d            stem_ln_kernel
+//   K4  depthwise 7x7 + LayerNorm               dwconv7_ln_kernel
+//   K6  LayerNorm2d + 2x2 space-to-depth        ln_patchify_kernel   (conv2x2s2 itself is a GEMM)
+//   K7  global-avg-pool + LayerNorm2d           pool_ln_kernel       (fc is a GEMM)
+//   K1/K9 first 3->16 conv (Cin=3 is not MFMA-shaped)   conv3_first_kernel
+//   K2/K12 last 16->3 ConvTranspose2d           convt2_small_kernel
+//   K10/K11 split-K reduce + bias + reparameterise      reparam_kernel, kl_rows_kernel
+//   K8  500->2 head tail                        head_tail_kernel
+//   K13/K14 bilinear 112->224 (+ per-frame MSE) resize_mse_kernel
+//   K15 sigmoid -> mean over rows               vote_kernel
+#pragma once
+#include "common.h"
+
+namespace gcv {
+
+// ------------------------------------------------------------------ K3: stem
+// conv 4x4 stride 4 (3 -> 96) + LayerNorm over the 96 channels, output NHWC tokens.
+// Input addressed by element strides so NCHW frames and the NHWC reconstruction both work.
+// wp: [48][96] fp32 with k = ci*16 + ky*4 + kx.
+template <typename T>
+__global__ void __launch_bounds__(256) stem_ln_kernel(const T* __restrict__ x, int64_t sb, int64_t sc, int64_t sy,
+                                                      int64_t sx, const float* __restrict__ wp,
+                                                      const float* __restrict__ bias, const float* __restrict__ lnw,
+                                                      const float* __restrict__ lnb, T* __restrict__ out, int nimg,
+                                                      int Ho, int Wo, float eps) {
+  __shared__ float sW[48 * 96];
+  __shared__ float sIn[32][49];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 48 * 96; i += 256) sW[i] = wp[i];
+  const int64_t total = (int64_t)nimg * Ho * Wo;
+  const int64_t p0 = (int64_t)blockIdx.x * 32;
+  for (int e = tid; e < 32 * 48; e += 256) {
+    const int p = e / 48, k = e - p * 48;
+    const int64_t gp = p0 + p;
+    float v = 0.0f;
+    if (gp < total) {
+      const int xo = (int)(gp % Wo);
+      const int64_t t = gp / Wo;
+      const int yo = (int)(t % Ho);
+      const int64_t b = t / Ho;
+      const int ci = k >> 4, ky = (k >> 2) & 3, kx = k & 3;
+      v = to_f(x[b * sb + ci * sc + (int64_t)(4 * yo + ky) * sy + (int64_t)(4 * xo + kx) * sx]);
+    }
+    sIn[p][k] = v;
+  }
+  __syncthreads();
+  const int p = tid >> 3, cg = tid & 7;
+  float acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = bias[cg * 12 + i];
+#pragma unroll 4
+  for (int k = 0; k < 48; ++k) {
+    const float xv = sIn[p][k];
+    const float* wr = sW + k * 96 + cg * 12;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = fmaf(xv, wr[i], acc[i]);
+  }
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s += acc[i];
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+  const float mean = s * (1.0f / 96.0f);
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) { const float d = acc[i] - mean; q = fmaf(d, d, q); }
+  q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+  const float rstd = 1.0f / sqrtf(q * (1.0f / 96.0f) + eps);
+  const int64_t gp = p0 + p;
+  if (gp < total) {
+    T* o = out + gp * 96 + cg * 12;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int c = cg * 12 + i;
+      o[i] = from_f<T>((acc[i] - mean) * rstd * lnw[c] + lnb[c]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ K4: dwconv7x7 + LN
+// NHWC.  One thread per channel of a 7x7 output tile: the 49 taps of that channel live in
+// registers, every input value of the 13x13 halo window is loaded once (lanes = consecutive
+// channels -> coalesced) and scattered into the <=49 accumulators it touches.  LayerNorm over
+// channels: conv outputs staged in LDS [pixel][C], 32-lane groups reduce a pixel each
+// (two-pass mean / variance), every thread then normalises its own registers.
+// C=96 packs two tiles per workgroup (192 threads) so no lanes idle.
+template <typename T, int C>
+__global__ void __launch_bounds__((C == 96) ? 192 : C, (C == 768) ? 3 : 2)
+dwconv7_ln_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*[49][C]*/,
+                  const float* __restrict__ bdw, const float* __restrict__ lnw, const float* __restrict__ lnb,
+                  T* __restrict__ y, int nimg, int H, int W, float eps) {
+  constexpr int TILES = (C == 96) ? 2 : 1;
+  constexpr int TPB = C * TILES;
+  constexpr int NP = TILES * 49;
+  extern __shared__ __attribute__((aligned(16))) float dw_lds[];   // [NP][C] values, then [NP][2] stats
+  float* stats = dw_lds + NP * C;
+
+  const int tid = threadIdx.x;
+  const int tslot = tid / C;
+  const int c = tid - tslot * C;
+  const int tiles_x = (W + 6) / 7, tiles_y = (H + 6) / 7;
+  const int total = nimg * tiles_x * tiles_y;
+  const int tile_raw = blockIdx.x * TILES + tslot;
+  const bool tile_ok = tile_raw < total;
+  const int tile = tile_ok ? tile_raw : total - 1;   // idle slot recomputes the last tile, stores nothing
+  const int tx = tile % tiles_x, t2 = tile / tiles_x;
+  const int ty = t2 % tiles_y, b = t2 / tiles_y;
+  const int x0 = tx * 7, y0 = ty * 7;
+
+  float w[49];
+#pragma unroll
+  for (int t = 0; t < 49; ++t) w[t] = wdw[t * C + c];
+  const float bv = bdw[c];
+
+  // 13x13 halo window, fully unrolled so acc[]/w[] stay in registers; loads are issued one halo
+  // row ahead and fenced per row (sched_barrier) so the compiler cannot hoist all 169 of them.
+  float acc[49];
+#pragma unroll
+  for (int t = 0; t < 49; ++t) acc[t] = bv;
+  const T* xb = x + (int64_t)b * H * W * C + c;
+  // branch-free halo loads: clamp the address into the image, zero the value by select
+  // (multiplying by a 0/1 mask instead of selecting keeps the loads unconditional: one basic block)
+  int xoff[13];
+  float xmask[13];
+#pragma unroll
+  for (int s = 0; s < 13; ++s) {
+    const int ix = x0 + s - 3;
+    xmask[s] = (ix >= 0 && ix < W) ? 1.0f : 0.0f;
+    xoff[s] = min(max(ix, 0), W - 1) * C;
+  }
+  float vn[13];
+  {
+    const int iy = y0 - 3;
+    const float rmask = (iy >= 0 && iy < H) ? 1.0f : 0.0f;
+    const T* rp = xb + (int64_t)min(max(iy, 0), H - 1) * W * C;
+#pragma unroll
+    for (int s = 0; s < 13; ++s) vn[s] = to_f(rp[xoff[s]]) * (rmask * xmask[s]);
+  }
+#pragma unroll
+  for (int r = 0; r < 13; ++r) {
+    float v[13];
+#pragma unroll
+    for (int s = 0; s < 13; ++s) v[s] = vn[s];
+    if (r + 1 < 13) {
+      const int iy = y0 + r - 2;
+      const float rmask = (iy >= 0 && iy < H) ? 1.0f : 0.0f;
+      const T* rp = xb + (int64_t)min(max(iy, 0), H - 1) * W * C;
+#pragma unroll
+      for (int s = 0; s < 13; ++s) vn[s] = to_f(rp[xoff[s]]) * (rmask * xmask[s]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) {
+#pragma unroll
+      for (int sx = 0; sx < 13; ++sx) {
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+          const int oy = r - ky, ox = sx - kx;
+          if (oy >= 0 && oy < 7 && ox >= 0 && ox < 7)
+            acc[oy * 7 + ox] = fmaf(v[sx], w[ky * 7 + kx], acc[oy * 7 + ox]);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float* sval = dw_lds + tslot * 49 * C;
+#pragma unroll
+  for (int p = 0; p < 49; ++p) sval[p * C + c] = acc[p];
+  __syncthreads();
+
+  const int grp = tid >> 5, gl = tid & 31;
+  constexpr int NG = TPB / 32;
+  for (int p = grp; p < NP; p += NG) {
+    const float* row = dw_lds + p * C;
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < C / 32; ++k) s += row[gl + 32 * k];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * (1.0f / C);
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < C / 32; ++k) { const float d = row[gl + 32 * k] - mean; q = fmaf(d, d, q); }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    if (gl == 0) {
+      stats[2 * p] = mean;
+      stats[2 * p + 1] = 1.0f / sqrtf(q * (1.0f / C) + eps);
+    }
+  }
+  __syncthreads();
+
+  if (tile_ok) {
+    const float lw = lnw[c], lb = lnb[c];
+    T* yb = y + (int64_t)b * H * W * C + c;
+#pragma unroll
+    for (int p = 0; p < 49; ++p) {
+      const int oy = y0 + p / 7, ox = x0 + p % 7;
+      if (oy < H && ox < W) {
+        const float mean = stats[2 * (tslot * 49 + p)], rstd = stats[2 * (tslot * 49 + p) + 1];
+        yb[((int64_t)oy * W + ox) * C] = from_f<T>((acc[p] - mean) * rstd * lw + lb);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ K6: LN2d + space-to-depth
+// x (nimg,H,W,C) -> out (nimg,H/2,W/2,4C), K index (dy*2+dx)*C + c; floor(H/2): an odd last
+// row/col is dropped exactly as Conv2d(k=2,s=2) drops it (7 -> 3 in the 112-px pass).
+template <typename T>
+__global__ void __launch_bounds__(256) ln_patchify_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bvec, T* __restrict__ out,
+                                                          int nimg, int H, int W, int C, float eps) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t pix = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t total = (int64_t)nimg * H * W;
+  if (pix >= total) return;
+  const int ix = (int)(pix % W);
+  const int64_t t = pix / W;
+  const int iy = (int)(t % H);
+  const int64_t b = t / H;
+  const int Ho = H >> 1, Wo = W >> 1;
+  if (iy >= 2 * Ho || ix >= 2 * Wo) return;
+  const T* src = x + pix * C;
+  float v[12];
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const int c = lane + 64 * k;
+    v[k] = (c < C) ? to_f(src[c]) : 0.0f;
+    s += v[k];
+  }
+  s = wave_sum(s);
+  const float mean = s / (float)C;
+  float q = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const int c = lane + 64 * k;
+    const float d = (c < C) ? v[k] - mean : 0.0f;
+    q = fmaf(d, d, q);
+  }
+  q = wave_sum(q);
+  const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+  T* dst = out + ((b * Ho + (iy >> 1)) * Wo + (ix >> 1)) * 4 * C + ((iy & 1) * 2 + (ix & 1)) * C;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const int c = lane + 64 * k;
+    if (c < C) dst[c] = from_f<T>((v[k] - mean) * rstd * w[c] + bvec[c]);
+  }
+}
+
+// ------------------------------------------------------------------ generic row LayerNorm (Swin)
+template <typename T>
+__global__ void __launch_bounds__(256) layernorm_rows_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bvec, T* __restrict__ out,
+                                                             int64_t rows, int C, float eps) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const T* src = x + row * C;
+  float v[24];
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 24; ++k) {
+    const int c = lane + 64 * k;
+    v[k] = (c < C) ? to_f(src[c]) : 0.0f;
+    s += v[k];
+  }
+  s = wave_sum(s);
+  const float mean = s / (float)C;
+  float q = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 24; ++k) {
+    const int c = lane + 64 * k;
+    const float d = (c < C) ? v[k] - mean : 0.0f;
+    q = fmaf(d, d, q);
+  }
+  q = wave_sum(q);
+  const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+  T* dst = out + row * C;
+#pragma unroll
+  for (int k = 0; k < 24; ++k) {
+    const int c = lane + 64 * k;
+    if (c < C) dst[c] = from_f<T>((v[k] - mean) * rstd * w[c] + bvec[c]);
+  }
+}
+
+// ------------------------------------------------------------------ K7: avg-pool + LN(768)
+template <typename T>
+__global__ void __launch_bounds__(256) pool_ln_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ bvec, T* __restrict__ out, int HW,
+                                                      int C /*768*/, float eps) {
+  __shared__ float red[8];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const T* src = x + (int64_t)b * HW * C;
+  float m[3] = {0.f, 0.f, 0.f};
+  for (int p = 0; p < HW; ++p) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) m[k] += to_f(src[(int64_t)p * C + tid + 256 * k]);
+  }
+  const float inv = 1.0f / (float)HW;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) m[k] *= inv;
+  float s = wave_sum(m[0] + m[1] + m[2]);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C;
+  float q = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { const float d = m[k] - mean; q = fmaf(d, d, q); }
+  q = wave_sum(q);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = q;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf((red[4] + red[5] + red[6] + red[7]) / (float)C + eps);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int c = tid + 256 * k;
+    out[(int64_t)b * C + c] = from_f<T>((m[k] - mean) * rstd * w[c] + bvec[c]);
+  }
+}
+
+// ------------------------------------------------------------------ K1/K9 first conv (Cin = 3)
+// POOL=true : Conv2d(3,16,3,s1,p1) -> ReLU -> MaxPool2 (ED encoder layer 1), thread = pooled pixel
+// POOL=false: Conv2d(3,16,3,s2,p1) (+folded BN) -> LeakyReLU (VAE encoder layer 1)
+// wp: [27][16] fp32 with k = (ky*3+kx)*3 + ci; output NHWC (nimg,Ho,Wo,16).
+template <typename T, bool POOL>
+__global__ void __launch_bounds__(256) conv3_first_kernel(const T* __restrict__ x, int64_t sb, int64_t sc, int64_t sy,
+                                                          int64_t sx, const float* __restrict__ wp,
+                                                          const float* __restrict__ bias, T* __restrict__ out,
+                                                          int nimg, int H, int W, int act) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const int64_t total = (int64_t)nimg * Ho * Wo;
+  const int64_t gp = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gp >= total) return;
+  const int xo = (int)(gp % Wo);
+  const int64_t t = gp / Wo;
+  const int yo = (int)(t % Ho);
+  const int64_t b = t / Ho;
+  constexpr int PW = POOL ? 4 : 3;      // input patch width/height
+  float in[PW][PW][3];
+  const int iy0 = 2 * yo - 1, ix0 = 2 * xo - 1;
+#pragma unroll
+  for (int r = 0; r < PW; ++r)
+#pragma unroll
+    for (int s = 0; s < PW; ++s) {
+      const int iy = iy0 + r, ix = ix0 + s;
+      const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci)
+        in[r][s][ci] = ok ? to_f(x[b * sb + ci * sc + (int64_t)iy * sy + (int64_t)ix * sx]) : 0.0f;
+    }
+  float res[16];
+  constexpr int NPOS = POOL ? 4 : 1;
+#pragma unroll
+  for (int q = 0; q < NPOS; ++q) {
+    const int dy = q >> 1, dx = q & 1;
+    float acc[16];
+#pragma unroll
+    for (int co = 0; co < 16; ++co) acc[co] = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+          const float v = in[dy + ky][dx + kx][ci];
+          const float* wr = wp + ((ky * 3 + kx) * 3 + ci) * 16;
+#pragma unroll
+          for (int co = 0; co < 16; ++co) acc[co] = fmaf(v, wr[co], acc[co]);
+        }
+#pragma unroll
+    for (int co = 0; co < 16; ++co) res[co] = (q == 0) ? acc[co] : fmaxf(res[co], acc[co]);
+  }
+  T* o = out + gp * 16;
+#pragma unroll
+  for (int co = 0; co < 16; ++co) o[co] = from_f<T>(apply_act(res[co] + bias[co], act));
+}
+
+// ------------------------------------------------------------------ K2/K12 last ConvTranspose2d 16 -> 3
+// x NHWC (nimg,H,W,16) -> out NHWC (nimg,2H,2W,3); wp: [16][2][2][3] fp32 (ci,dy,dx,co).
+template <typename T>
+__global__ void __launch_bounds__(256) convt2_small_kernel(const T* __restrict__ x, const float* __restrict__ wp,
+                                                           const float* __restrict__ bias, T* __restrict__ out,
+                                                           int nimg, int H, int W, int act) {
+  const int64_t total = (int64_t)nimg * H * W;
+  const int64_t gp = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gp >= total) return;
+  const int xi = (int)(gp % W);
+  const int64_t t = gp / W;
+  const int yi = (int)(t % H);
+  const int64_t b = t / H;
+  float v[16];
+  const T* src = x + gp * 16;
+#pragma unroll
+  for (int ci = 0; ci < 16; ++ci) v[ci] = to_f(src[ci]);
+  float acc[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) acc[j] = bias[j % 3];
+#pragma unroll
+  for (int ci = 0; ci < 16; ++ci)
+#pragma unroll
+    for (int j = 0; j < 12; ++j) acc[j] = fmaf(v[ci], wp[ci * 12 + j], acc[j]);
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy) {
+    T* o = out + ((b * 2 * H + 2 * yi + dy) * 2 * W + 2 * xi) * 3;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) o[j] = from_f<T>(apply_act(acc[dy * 6 + j], act));
+  }
+}
+
+// ------------------------------------------------------------------ K10/K11 split-K reduce + reparam
+// mu[b][n] = sum_s partial[s][b][n] + bias[n];  z = eps*exp(0.5*mu) + mu  (reference quirk:
+// std from mu, model/genconvit_vae.py:45).  z is written in NHWC order for the decoder's
+// Unflatten(256,7,7): n = c*49 + hw  ->  hw*256 + c.
+template <typename T>
+__global__ void __launch_bounds__(256) reparam_kernel(const float* __restrict__ partial, int splitk,
+                                                      const float* __restrict__ bias, const float* __restrict__ eps,
+                                                      float* __restrict__ mu_out, T* __restrict__ z_nhwc, int B,
+                                                      int N /*12544*/) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)B * N;
+  if (i >= total) return;
+  const int n = (int)(i % N);
+  const int64_t b = i / N;
+  float mu = bias[n];
+  for (int s = 0; s < splitk; ++s) mu += partial[(int64_t)s * total + i];
+  if (mu_out) mu_out[i] = mu;
+  const float z = fmaf(eps[i], expf(0.5f * mu), mu);
+  const int c = n / 49, hw = n - c * 49;
+  z_nhwc[b * N + hw * 256 + c] = from_f<T>(z);
+}
+
+// rowsum[b] = sum_n (1 + var - mu^2 - exp(var)), var from split-K slabs (genconvit_vae.py:58)
+static __global__ void __launch_bounds__(256) kl_rows_kernel(const float* __restrict__ partial, int splitk,
+                                                      const float* __restrict__ bias, const float* __restrict__ mu,
+                                                      float* __restrict__ rowsum, int B, int N) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int64_t total = (int64_t)B * N;
+  float s = 0.0f;
+  for (int n = tid; n < N; n += 256) {
+    const int64_t i = (int64_t)b * N + n;
+    float var = bias[n];
+    for (int k = 0; k < splitk; ++k) var += partial[(int64_t)k * total + i];
+    const float m = mu[i];
+    s += 1.0f + var - m * m - expf(var);
+  }
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) rowsum[b] = red[0] + red[1] + red[2] + red[3];
+}
+
+// kl = 0.5 * mean_b(-0.5 * rowsum[b])   (kl_weight = 0.5, genconvit_vae.py:40,58)
+static __global__ void kl_finish_kernel(const float* __restrict__ rowsum, float* __restrict__ kl, int B) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) s += -0.5f * rowsum[b];
+    *kl = 0.5f * s / (float)B;
+  }
+}
+
+// ------------------------------------------------------------------ K8 tail: 500 -> 2
+template <typename T>
+__global__ void __launch_bounds__(256) head_tail_kernel(const T* __restrict__ h, const float* __restrict__ w /*[2][K]*/,
+                                                        const float* __restrict__ bias, float* __restrict__ logits,
+                                                        int B, int K) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  float a0 = 0.0f, a1 = 0.0f;
+  for (int k = lane; k < K; k += 64) {
+    const float v = to_f(h[(int64_t)b * K + k]);
+    a0 = fmaf(v, w[k], a0);
+    a1 = fmaf(v, w[K + k], a1);
+  }
+  a0 = wave_sum(a0);
+  a1 = wave_sum(a1);
+  if (lane == 0) {
+    logits[2 * b] = a0 + bias[0];
+    logits[2 * b + 1] = a1 + bias[1];
+  }
+}
+
+// ------------------------------------------------------------------ K13/K14 bilinear x2 + MSE
+// x_hat NHWC (B,112,112,3) -> recon NCHW (B,3,224,224) (nullable) ; msepart[b][blk] partial sums of
+// (recon - img)^2 over the block's pixels (nullable), img NCHW (B,3,224,224).
+template <typename T>
+__global__ void __launch_bounds__(256) resize_mse_kernel(const T* __restrict__ xhat, const T* __restrict__ img,
+                                                         T* __restrict__ recon, float* __restrict__ msepart) {
+  __shared__ float red[4];
+  const int b = blockIdx.y;
+  const int pix = blockIdx.x * 256 + threadIdx.x;           // 224*224 = 196 * 256
+  const int oy = pix / 224, ox = pix - oy * 224;
+  // align_corners=False, scale 0.5: src = (dst + 0.5) * 0.5 - 0.5, clamped below at 0
+  float sy = fmaxf((oy + 0.5f) * 0.5f - 0.5f, 0.0f), sx = fmaxf((ox + 0.5f) * 0.5f - 0.5f, 0.0f);
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = min(y0 + 1, 111), x1 = min(x0 + 1, 111);
+  const float ly = sy - y0, lx = sx - x0;
+  const T* base = xhat + (int64_t)b * 112 * 112 * 3;
+  float err = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v00 = to_f(base[(y0 * 112 + x0) * 3 + c]), v01 = to_f(base[(y0 * 112 + x1) * 3 + c]);
+    const float v10 = to_f(base[(y1 * 112 + x0) * 3 + c]), v11 = to_f(base[(y1 * 112 + x1) * 3 + c]);
+    const float top = v00 + (v01 - v00) * lx, bot = v10 + (v11 - v10) * lx;
+    const float v = top + (bot - top) * ly;
+    const int64_t o = (((int64_t)b * 3 + c) * 224 + oy) * 224 + ox;
+    if (recon) recon[o] = from_f<T>(v);
+    if (msepart) { const float d = v - to_f(img[o]); err = fmaf(d, d, err); }
+  }
+  if (msepart) {
+    err = wave_sum(err);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = err;
+    __syncthreads();
+    if (threadIdx.x == 0) msepart[b * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+  }
+}
+
+static __global__ void __launch_bounds__(256) mse_finish_kernel(const float* __restrict__ msepart, float* __restrict__ mse,
+                                                         int nblk, float inv_count) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  float s = 0.0f;
+  for (int i = threadIdx.x; i < nblk; i += 256) s += msepart[b * nblk + i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) mse[b] = (red[0] + red[1] + red[2] + red[3]) * inv_count;
+}
+
+// ------------------------------------------------------------------ K15 vote: mean over rows of sigmoid
+static __global__ void __launch_bounds__(256) vote_kernel(const float* __restrict__ logits, int rows,
+                                                   float* __restrict__ mean2) {
+  __shared__ float red[8];
+  float s0 = 0.0f, s1 = 0.0f;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    s0 += 1.0f / (1.0f + expf(-logits[2 * r]));
+    s1 += 1.0f / (1.0f + expf(-logits[2 * r + 1]));
+  }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s0; red[4 + (threadIdx.x >> 6)] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mean2[0] = (red[0] + red[1] + red[2] + red[3]) / (float)rows;
+    mean2[1] = (red[4] + red[5] + red[6] + red[7]) / (float)rows;
+  }
+}
+
+}  // namespace gcv

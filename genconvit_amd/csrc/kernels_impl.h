@@ -1,0 +1,157 @@
+// Launch wrappers for kernels.h (included by kern_{f32,f16,bf16}.hip).
+#pragma once
+#include "kernels.h"
+#include "kernels_dev.h"
+
+namespace gcv {
+
+template <typename T>
+int launch_stem_ln(const T* x, int64_t sb, int64_t sc, int64_t sy, int64_t sx, const float* wp, const float* bias,
+                   const float* lnw, const float* lnb, T* out, int nimg, int Ho, int Wo, float eps, hipStream_t s) {
+  const int64_t total = (int64_t)nimg * Ho * Wo;
+  GCV_REQUIRE(total > 0, "stem: empty");
+  hipLaunchKernelGGL((stem_ln_kernel<T>), dim3((unsigned)cdiv64(total, 32)), dim3(256), 0, s, x, sb, sc, sy, sx, wp,
+                     bias, lnw, lnb, out, nimg, Ho, Wo, eps);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T, int C>
+static int launch_dw_c(const T* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb, T* y,
+                       int nimg, int H, int W, float eps, hipStream_t s) {
+  constexpr int TILES = (C == 96) ? 2 : 1;
+  constexpr int TPB = C * TILES;
+  constexpr size_t LDS = (size_t)TILES * 49 * C * 4 + (size_t)TILES * 49 * 2 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (LDS > 64 * 1024)
+      GCV_CHECK_HIP(hipFuncSetAttribute((const void*)dwconv7_ln_kernel<T, C>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    attr_set = true;
+  }
+  const int tiles = nimg * cdiv(H, 7) * cdiv(W, 7);
+  hipLaunchKernelGGL((dwconv7_ln_kernel<T, C>), dim3(cdiv(tiles, TILES)), dim3(TPB), LDS, s, x, wdw, bdw, lnw, lnb, y,
+                     nimg, H, W, eps);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int launch_dwconv7_ln(const T* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb, T* y,
+                      int nimg, int H, int W, int C, float eps, hipStream_t s) {
+  GCV_REQUIRE(nimg > 0 && H > 0 && W > 0, "dwconv: empty");
+  switch (C) {
+    case 96:  return launch_dw_c<T, 96>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
+    case 192: return launch_dw_c<T, 192>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
+    case 384: return launch_dw_c<T, 384>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
+    case 768: return launch_dw_c<T, 768>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
+  }
+  set_error("dwconv7_ln: C must be one of 96/192/384/768");
+  return -3;
+}
+
+template <typename T>
+int launch_ln_patchify(const T* x, const float* w, const float* b, T* out, int nimg, int H, int W, int C, float eps,
+                       hipStream_t s) {
+  GCV_REQUIRE(C <= 768 && nimg > 0, "ln_patchify: C <= 768");
+  const int64_t total = (int64_t)nimg * H * W;
+  hipLaunchKernelGGL((ln_patchify_kernel<T>), dim3((unsigned)cdiv64(total, 4)), dim3(256), 0, s, x, w, b, out, nimg, H,
+                     W, C, eps);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int launch_layernorm_rows(const T* x, const float* w, const float* b, T* out, int64_t rows, int C, float eps,
+                          hipStream_t s) {
+  GCV_REQUIRE(C <= 1536 && rows > 0, "layernorm_rows: C <= 1536");
+  hipLaunchKernelGGL((layernorm_rows_kernel<T>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, x, w, b, out, rows,
+                     C, eps);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int launch_pool_ln(const T* x, const float* w, const float* b, T* out, int nimg, int HW, int C, float eps,
+                   hipStream_t s) {
+  GCV_REQUIRE(C == 768 && nimg > 0 && HW > 0, "pool_ln: C == 768");
+  hipLaunchKernelGGL((pool_ln_kernel<T>), dim3(nimg), dim3(256), 0, s, x, w, b, out, HW, C, eps);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int launch_conv3_first(const T* x, int64_t sb, int64_t sc, int64_t sy, int64_t sx, const float* wp, const float* bias,
+                       T* out, int nimg, int H, int W, bool pool, int act, hipStream_t s) {
+  GCV_REQUIRE(H % 2 == 0 && W % 2 == 0 && nimg > 0, "conv3_first: even H, W");
+  const int64_t total = (int64_t)nimg * (H / 2) * (W / 2);
+  const dim3 grid((unsigned)cdiv64(total, 256));
+  if (pool)
+    hipLaunchKernelGGL((conv3_first_kernel<T, true>), grid, dim3(256), 0, s, x, sb, sc, sy, sx, wp, bias, out, nimg, H,
+                       W, act);
+  else
+    hipLaunchKernelGGL((conv3_first_kernel<T, false>), grid, dim3(256), 0, s, x, sb, sc, sy, sx, wp, bias, out, nimg,
+                       H, W, act);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int launch_convt2_small(const T* x, const float* wp, const float* bias, T* out, int nimg, int H, int W, int act,
+                        hipStream_t s) {
+  const int64_t total = (int64_t)nimg * H * W;
+  GCV_REQUIRE(total > 0, "convt2_small: empty");
+  hipLaunchKernelGGL((convt2_small_kernel<T>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, x, wp, bias, out,
+                     nimg, H, W, act);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int launch_reparam(const float* partial, int splitk, const float* bias, const float* eps, float* mu_out, T* z_nhwc,
+                   int B, int N, hipStream_t s) {
+  GCV_REQUIRE(N == 12544 && B > 0, "reparam: latent 12544 = 256*7*7");
+  const int64_t total = (int64_t)B * N;
+  hipLaunchKernelGGL((reparam_kernel<T>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, partial, splitk, bias,
+                     eps, mu_out, z_nhwc, B, N);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int launch_head_tail(const T* h, const float* w, const float* bias, float* logits, int B, int K, hipStream_t s) {
+  GCV_REQUIRE(B > 0, "head_tail: empty");
+  hipLaunchKernelGGL((head_tail_kernel<T>), dim3(cdiv(B, 4)), dim3(256), 0, s, h, w, bias, logits, B, K);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int launch_resize_mse(const T* xhat, const T* img, T* recon, float* msepart, float* mse, int B, hipStream_t s) {
+  GCV_REQUIRE(B > 0, "resize: empty");
+  const int nblk = 224 * 224 / 256;   // 196
+  hipLaunchKernelGGL((resize_mse_kernel<T>), dim3(nblk, B), dim3(256), 0, s, xhat, img, recon, mse ? msepart : nullptr);
+  GCV_CHECK_HIP(hipGetLastError());
+  if (mse) {
+    hipLaunchKernelGGL(mse_finish_kernel, dim3(B), dim3(256), 0, s, msepart, mse, nblk, 1.0f / (3.0f * 224.0f * 224.0f));
+    GCV_CHECK_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+#define GCV_INSTANTIATE_KERNELS(T)                                                                                    \
+  template int launch_stem_ln<T>(const T*, int64_t, int64_t, int64_t, int64_t, const float*, const float*,            \
+                                 const float*, const float*, T*, int, int, int, float, hipStream_t);                  \
+  template int launch_dwconv7_ln<T>(const T*, const float*, const float*, const float*, const float*, T*, int, int,   \
+                                    int, int, float, hipStream_t);                                                    \
+  template int launch_ln_patchify<T>(const T*, const float*, const float*, T*, int, int, int, int, float, hipStream_t); \
+  template int launch_layernorm_rows<T>(const T*, const float*, const float*, T*, int64_t, int, float, hipStream_t);  \
+  template int launch_pool_ln<T>(const T*, const float*, const float*, T*, int, int, int, float, hipStream_t);        \
+  template int launch_conv3_first<T>(const T*, int64_t, int64_t, int64_t, int64_t, const float*, const float*, T*,    \
+                                     int, int, int, bool, int, hipStream_t);                                          \
+  template int launch_convt2_small<T>(const T*, const float*, const float*, T*, int, int, int, int, hipStream_t);     \
+  template int launch_reparam<T>(const float*, int, const float*, const float*, float*, T*, int, int, hipStream_t);   \
+  template int launch_head_tail<T>(const T*, const float*, const float*, float*, int, int, hipStream_t);              \
+  template int launch_resize_mse<T>(const T*, const T*, T*, float*, float*, int, hipStream_t);
+
+}  // namespace gcv

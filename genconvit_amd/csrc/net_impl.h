@@ -1,0 +1,754 @@
+// NetImpl<T>: weight packing + forward schedules (included by net_{f32,f16,bf16}.hip).
+//
+// Data layout in HBM
+//   activations : NHWC "token major" (tokens, C) in T; several images / passes that share a weight
+//                 set are concatenated along the token axis so pointwise GEMMs run once over all of them
+//   GEMM weights: (N, K) row-major in T (nn.Linear layout); conv weights re-ordered to K = (ky,kx,ci)
+//   small params: fp32 (biases, LayerNorm affine, layer-scale gamma, depthwise taps [49][C])
+//   workspace   : one arena sized by a dry run of both forwards at max_batch (no allocation per call)
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "gemm.h"
+#include "kernels.h"
+#include "net.h"
+#include "swin.h"
+
+namespace gcv {
+
+// ---------------------------------------------------------------- host conversions
+template <typename T> inline T host_cvt(float v);
+template <> inline float host_cvt<float>(float v) { return v; }
+template <> inline half_t host_cvt<half_t>(float v) { return (half_t)v; }
+template <> inline bf16_t host_cvt<bf16_t>(float v) {
+  uint32_t u;
+  std::memcpy(&u, &v, 4);
+  uint16_t h;
+  if ((u & 0x7fffffffu) > 0x7f800000u) h = (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+  else h = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);              // round to nearest even
+  bf16_t r;
+  std::memcpy(&r, &h, 2);
+  return r;
+}
+
+// ---------------------------------------------------------------- device memory owners
+struct WeightStore {
+  std::vector<void*> ptrs;
+  size_t bytes = 0;
+  ~WeightStore() { clear(); }
+  void clear() {
+    for (void* p : ptrs) (void)hipFree(p);
+    ptrs.clear();
+    bytes = 0;
+  }
+  void* raw(size_t n) {
+    void* p = nullptr;
+    if (hipMalloc(&p, n ? n : 16) != hipSuccess) return nullptr;
+    ptrs.push_back(p);
+    bytes += n;
+    return p;
+  }
+  template <typename U> U* upload(const std::vector<U>& h) {
+    U* p = (U*)raw(h.size() * sizeof(U));
+    if (!p) return nullptr;
+    if (hipMemcpy(p, h.data(), h.size() * sizeof(U), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return p;
+  }
+};
+
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0, peak = 0;
+  bool dry = false;
+  bool overflow = false;
+  size_t mark() const { return off; }
+  void release(size_t m) { off = m; }
+  void* alloc(size_t bytes) {
+    const size_t a = (off + 255) & ~(size_t)255;
+    off = a + bytes;
+    peak = std::max(peak, off);
+    if (!dry && off > cap) { overflow = true; return base; }
+    return base + a;
+  }
+  template <typename U> U* get(int64_t n) { return (U*)alloc((size_t)n * sizeof(U)); }
+};
+
+// device-side permute+cast for the 25088x12544 mu/var matrices: columns c*196+hw -> hw*128+c so the
+// NHWC encoder output (B,14,14,128) can be used as the GEMM A operand without a transpose.
+template <typename T>
+__global__ void __launch_bounds__(256) pack_mu_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t total) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= total) return;
+  const int64_t n = o / 25088;
+  const int k = (int)(o - n * 25088);
+  const int hw = k >> 7, c = k & 127;
+  dst[o] = from_f<T>(src[n * 25088 + c * 196 + hw]);
+}
+
+// ---------------------------------------------------------------- packed weights
+template <typename T> struct CnxBlockW {
+  float *dw_w, *dw_b, *ln_w, *ln_b, *fc1_b, *fc2_b, *gamma;
+  T *fc1_w, *fc2_w;
+};
+template <typename T> struct CnxW {
+  float *stem_w, *stem_b, *stem_lnw, *stem_lnb;
+  CnxBlockW<T> blk[18];
+  struct { float *ln_w, *ln_b, *b; T* w; } down[3];
+  float *head_lnw, *head_lnb, *head_fc_b;
+  T* head_fc_w;
+};
+template <typename T> struct HeadW {
+  T* fc_w;        // (500, 2000)
+  float* fc_b;
+  float* fc2_w;   // [2][500]
+  float* fc2_b;
+};
+template <typename T> struct EdW {
+  float *enc1_w, *enc1_b;            // [27][16]
+  T* enc_w[4];                       // layers 2..5 (Cout, 9*Cin)
+  float* enc_b[4];
+  T* dec_w[4];                       // layers 1..4 ((dy,dx,co), ci)
+  float* dec_b[4];
+  float *dec5_w, *dec5_b;            // [16][2][2][3]
+  HeadW<T> head;
+};
+template <typename T> struct VaeW {
+  float *enc1_w, *enc1_b;            // BN folded
+  T* enc_w[3];
+  float* enc_b[3];
+  T *mu_w, *var_w;                   // (12544, 25088) K-permuted
+  float *mu_b, *var_b;
+  T* dec_w[3];
+  float* dec_b[3];
+  float *dec4_w, *dec4_b;
+  HeadW<T> head;
+};
+
+static const int kDims[4] = {96, 192, 384, 768};
+static const int kDepths[4] = {3, 3, 9, 3};
+
+template <typename T> struct Seg {
+  const T* x;
+  int64_t sb, sc, sy, sx;   // element strides of the (n,3,H,W) input view
+  int n, H, W;
+  T* out;                   // backbone logits (n,1000) written at out + i*out_ld
+  int out_ld;
+  int act;
+};
+
+template <typename T> struct NetImpl : NetBase {
+  WeightStore ws_ed, ws_vae, ws_swin;
+  CnxW<T> bb_ed{}, bb_vae{};
+  EdW<T> ed{};
+  VaeW<T> vae{};
+  SwinW<T> swin{};
+  bool has_ed = false, has_vae = false, has_swin = false;
+  Arena arena;
+  hipStream_t cur = nullptr;
+
+  ~NetImpl() override {
+    if (arena.base) (void)hipFree(arena.base);
+  }
+
+  size_t workspace_bytes() const override { return arena.cap; }
+
+  // ------------------------------------------------------------ launch plumbing
+  template <class F> int run(const char* tag, double flops, double bytes, F&& f) {
+    if (arena.dry) return 0;
+    if (!prof.enabled) return f();
+    ProfRecord r;
+    r.tag = tag;
+    r.flops = flops;
+    r.bytes = bytes;
+    r.e0 = prof.get_event();
+    r.e1 = prof.get_event();
+    GCV_CHECK_HIP(hipEventRecord(r.e0, cur));
+    const int rc = f();
+    GCV_CHECK_HIP(hipEventRecord(r.e1, cur));
+    prof.recs.push_back(r);
+    return rc;
+  }
+
+  int gemm(const char* tag, const GemmArgs& g, int a_mode, int epi) {
+    const double flops = 2.0 * g.M * (double)g.N * g.K;
+    double a_bytes = (a_mode == A_PLAIN) ? (double)g.M * g.K : (double)g.M * (1 << g.cin_log2);
+    if (a_mode == A_IM2COL3_S2) a_bytes *= 4.0;     // input has 4x the pixels of the output
+    double c_bytes = (double)g.M * g.N;
+    if (epi == EPI_POOL4) c_bytes *= 0.25;
+    if (epi == EPI_RESID) c_bytes *= 2.0;
+    double bytes = sizeof(T) * (a_bytes + (double)g.N * g.K + c_bytes);
+    if (epi == EPI_SPLITK) bytes = sizeof(T) * (a_bytes + (double)g.N * g.K) + 4.0 * g.splitk * (double)g.M * g.N;
+    return run(tag, flops, bytes, [&] { return launch_gemm<T>(g, a_mode, epi, cur); });
+  }
+
+  // ------------------------------------------------------------ weight fetch helpers
+  static int fetch(const TensorMap& w, const std::string& name, int64_t numel, std::vector<float>& out) {
+    auto it = w.find(name);
+    if (it == w.end()) { set_error("missing weight tensor '" + name + "'"); return -4; }
+    if (it->second.numel != numel) {
+      set_error("weight tensor '" + name + "' has " + std::to_string(it->second.numel) + " elements, expected " +
+                std::to_string(numel));
+      return -4;
+    }
+    out.resize((size_t)numel);
+    if (it->second.on_device) GCV_CHECK_HIP(hipMemcpy(out.data(), it->second.data, numel * 4, hipMemcpyDeviceToHost));
+    else std::memcpy(out.data(), it->second.data, (size_t)numel * 4);
+    return 0;
+  }
+  static std::vector<T> cast_vec(const std::vector<float>& v) {
+    std::vector<T> o(v.size());
+    for (size_t i = 0; i < v.size(); ++i) o[i] = host_cvt<T>(v[i]);
+    return o;
+  }
+#define GCV_TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+#define GCV_UP(dst, store, vec) do { dst = (store).upload(vec); if (!(dst)) { set_error("hipMalloc/upload failed for " #dst); return -5; } } while (0)
+
+  int up_f32(const TensorMap& w, const std::string& name, int64_t n, WeightStore& st, float*& dst) {
+    std::vector<float> v;
+    GCV_TRY(fetch(w, name, n, v));
+    GCV_UP(dst, st, v);
+    return 0;
+  }
+  int up_cast(const TensorMap& w, const std::string& name, int64_t n, WeightStore& st, T*& dst) {
+    std::vector<float> v;
+    GCV_TRY(fetch(w, name, n, v));
+    std::vector<T> c = cast_vec(v);
+    GCV_UP(dst, st, c);
+    return 0;
+  }
+  // Conv2d weight (Cout,Cin,kh,kw) [* per-Cout scale] -> (Cout, (ky,kx,ci)) in T
+  int up_conv_gemm(const TensorMap& w, const std::string& name, int cout, int cin, int kh, int kw,
+                   const std::vector<float>* scale, WeightStore& st, T*& dst) {
+    std::vector<float> v;
+    GCV_TRY(fetch(w, name, (int64_t)cout * cin * kh * kw, v));
+    std::vector<T> o((size_t)cout * cin * kh * kw);
+    for (int co = 0; co < cout; ++co)
+      for (int ci = 0; ci < cin; ++ci)
+        for (int ky = 0; ky < kh; ++ky)
+          for (int kx = 0; kx < kw; ++kx) {
+            float x = v[(((size_t)co * cin + ci) * kh + ky) * kw + kx];
+            if (scale) x *= (*scale)[co];
+            o[(size_t)co * cin * kh * kw + ((size_t)(ky * kw + kx)) * cin + ci] = host_cvt<T>(x);
+          }
+    GCV_UP(dst, st, o);
+    return 0;
+  }
+  // ConvTranspose2d weight (Cin,Cout,2,2) -> ((dy,dx,co), ci) in T
+  int up_convt_gemm(const TensorMap& w, const std::string& name, int cin, int cout, WeightStore& st, T*& dst) {
+    std::vector<float> v;
+    GCV_TRY(fetch(w, name, (int64_t)cin * cout * 4, v));
+    std::vector<T> o((size_t)cin * cout * 4);
+    for (int ci = 0; ci < cin; ++ci)
+      for (int co = 0; co < cout; ++co)
+        for (int dy = 0; dy < 2; ++dy)
+          for (int dx = 0; dx < 2; ++dx)
+            o[((size_t)(dy * 2 + dx) * cout + co) * cin + ci] = host_cvt<T>(v[(((size_t)ci * cout + co) * 2 + dy) * 2 + dx]);
+    GCV_UP(dst, st, o);
+    return 0;
+  }
+  // ConvTranspose2d weight (16,3,2,2) -> [ci][dy][dx][co] fp32
+  int up_convt_small(const TensorMap& w, const std::string& name, WeightStore& st, float*& dst) {
+    std::vector<float> v;
+    GCV_TRY(fetch(w, name, 16 * 3 * 4, v));
+    std::vector<float> o(16 * 12);
+    for (int ci = 0; ci < 16; ++ci)
+      for (int co = 0; co < 3; ++co)
+        for (int dy = 0; dy < 2; ++dy)
+          for (int dx = 0; dx < 2; ++dx) o[ci * 12 + (dy * 2 + dx) * 3 + co] = v[((ci * 3 + co) * 2 + dy) * 2 + dx];
+    GCV_UP(dst, st, o);
+    return 0;
+  }
+  // first conv (16,3,3,3) [* scale] -> [27][16] fp32, k = (ky*3+kx)*3 + ci
+  int up_conv_first(const TensorMap& w, const std::string& name, const std::vector<float>* scale, WeightStore& st,
+                    float*& dst) {
+    std::vector<float> v;
+    GCV_TRY(fetch(w, name, 16 * 27, v));
+    std::vector<float> o(27 * 16);
+    for (int co = 0; co < 16; ++co)
+      for (int ci = 0; ci < 3; ++ci)
+        for (int ky = 0; ky < 3; ++ky)
+          for (int kx = 0; kx < 3; ++kx)
+            o[((ky * 3 + kx) * 3 + ci) * 16 + co] = v[((co * 3 + ci) * 3 + ky) * 3 + kx] * (scale ? (*scale)[co] : 1.0f);
+    GCV_UP(dst, st, o);
+    return 0;
+  }
+
+  int pack_convnext(const TensorMap& w, const std::string& p, WeightStore& st, CnxW<T>& o) {
+    {
+      std::vector<float> v, t(48 * 96);
+      GCV_TRY(fetch(w, p + "stem.0.weight", 96 * 48, v));
+      for (int co = 0; co < 96; ++co)
+        for (int k = 0; k < 48; ++k) t[k * 96 + co] = v[co * 48 + k];
+      GCV_UP(o.stem_w, st, t);
+    }
+    GCV_TRY(up_f32(w, p + "stem.0.bias", 96, st, o.stem_b));
+    GCV_TRY(up_f32(w, p + "stem.1.weight", 96, st, o.stem_lnw));
+    GCV_TRY(up_f32(w, p + "stem.1.bias", 96, st, o.stem_lnb));
+    int bi = 0;
+    for (int i = 0; i < 4; ++i) {
+      const int C = kDims[i];
+      if (i > 0) {
+        const int Cp = kDims[i - 1];
+        const std::string d = p + "stages." + std::to_string(i) + ".downsample.";
+        GCV_TRY(up_f32(w, d + "0.weight", Cp, st, o.down[i - 1].ln_w));
+        GCV_TRY(up_f32(w, d + "0.bias", Cp, st, o.down[i - 1].ln_b));
+        GCV_TRY(up_conv_gemm(w, d + "1.weight", C, Cp, 2, 2, nullptr, st, o.down[i - 1].w));
+        GCV_TRY(up_f32(w, d + "1.bias", C, st, o.down[i - 1].b));
+      }
+      for (int j = 0; j < kDepths[i]; ++j, ++bi) {
+        const std::string b = p + "stages." + std::to_string(i) + ".blocks." + std::to_string(j) + ".";
+        CnxBlockW<T>& k = o.blk[bi];
+        {
+          std::vector<float> v, t((size_t)49 * C);
+          GCV_TRY(fetch(w, b + "conv_dw.weight", (int64_t)C * 49, v));
+          for (int c = 0; c < C; ++c)
+            for (int q = 0; q < 49; ++q) t[(size_t)q * C + c] = v[(size_t)c * 49 + q];
+          GCV_UP(k.dw_w, st, t);
+        }
+        GCV_TRY(up_f32(w, b + "conv_dw.bias", C, st, k.dw_b));
+        GCV_TRY(up_f32(w, b + "norm.weight", C, st, k.ln_w));
+        GCV_TRY(up_f32(w, b + "norm.bias", C, st, k.ln_b));
+        GCV_TRY(up_cast(w, b + "mlp.fc1.weight", (int64_t)4 * C * C, st, k.fc1_w));
+        GCV_TRY(up_f32(w, b + "mlp.fc1.bias", 4 * C, st, k.fc1_b));
+        GCV_TRY(up_cast(w, b + "mlp.fc2.weight", (int64_t)4 * C * C, st, k.fc2_w));
+        GCV_TRY(up_f32(w, b + "mlp.fc2.bias", C, st, k.fc2_b));
+        GCV_TRY(up_f32(w, b + "gamma", C, st, k.gamma));
+      }
+    }
+    GCV_TRY(up_f32(w, p + "head.norm.weight", 768, st, o.head_lnw));
+    GCV_TRY(up_f32(w, p + "head.norm.bias", 768, st, o.head_lnb));
+    GCV_TRY(up_cast(w, p + "head.fc.weight", 1000 * 768, st, o.head_fc_w));
+    GCV_TRY(up_f32(w, p + "head.fc.bias", 1000, st, o.head_fc_b));
+    return 0;
+  }
+
+  int pack_head(const TensorMap& w, WeightStore& st, HeadW<T>& h) {
+    GCV_TRY(up_cast(w, "fc.weight", 500 * 2000, st, h.fc_w));
+    GCV_TRY(up_f32(w, "fc.bias", 500, st, h.fc_b));
+    GCV_TRY(up_f32(w, "fc2.weight", 2 * 500, st, h.fc2_w));
+    GCV_TRY(up_f32(w, "fc2.bias", 2, st, h.fc2_b));
+    return 0;
+  }
+
+  int load_ed(const TensorMap& w) override {
+    GCV_CHECK_HIP(hipSetDevice(device));
+    has_ed = false;
+    ws_ed.clear();
+    GCV_TRY(up_conv_first(w, "encoder.features.0.weight", nullptr, ws_ed, ed.enc1_w));
+    GCV_TRY(up_f32(w, "encoder.features.0.bias", 16, ws_ed, ed.enc1_b));
+    const int ech[5] = {16, 32, 64, 128, 256};
+    const int eidx[4] = {3, 6, 9, 12};
+    for (int l = 0; l < 4; ++l) {
+      const std::string n = "encoder.features." + std::to_string(eidx[l]);
+      GCV_TRY(up_conv_gemm(w, n + ".weight", ech[l + 1], ech[l], 3, 3, nullptr, ws_ed, ed.enc_w[l]));
+      GCV_TRY(up_f32(w, n + ".bias", ech[l + 1], ws_ed, ed.enc_b[l]));
+    }
+    const int dch[5] = {256, 128, 64, 32, 16};
+    const int didx[4] = {0, 2, 4, 6};
+    for (int l = 0; l < 4; ++l) {
+      const std::string n = "decoder.features." + std::to_string(didx[l]);
+      GCV_TRY(up_convt_gemm(w, n + ".weight", dch[l], dch[l + 1], ws_ed, ed.dec_w[l]));
+      GCV_TRY(up_f32(w, n + ".bias", dch[l + 1], ws_ed, ed.dec_b[l]));
+    }
+    GCV_TRY(up_convt_small(w, "decoder.features.8.weight", ws_ed, ed.dec5_w));
+    GCV_TRY(up_f32(w, "decoder.features.8.bias", 3, ws_ed, ed.dec5_b));
+    GCV_TRY(pack_convnext(w, "backbone.", ws_ed, bb_ed));
+    GCV_TRY(pack_head(w, ws_ed, ed.head));
+    has_ed = true;
+    return 0;
+  }
+
+  int pack_mu(const TensorMap& w, const std::string& name, T*& dst) {
+    auto it = w.find(name);
+    const int64_t total = (int64_t)12544 * 25088;
+    if (it == w.end() || it->second.numel != total) { set_error("missing or mis-sized '" + name + "'"); return -4; }
+    dst = (T*)ws_vae.raw((size_t)total * sizeof(T));
+    if (!dst) { set_error("hipMalloc failed for " + name); return -5; }
+    const float* src = it->second.data;
+    float* tmp = nullptr;
+    if (!it->second.on_device) {
+      GCV_CHECK_HIP(hipMalloc((void**)&tmp, (size_t)total * 4));
+      GCV_CHECK_HIP(hipMemcpy(tmp, src, (size_t)total * 4, hipMemcpyHostToDevice));
+      src = tmp;
+    }
+    hipLaunchKernelGGL((pack_mu_kernel<T>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, 0, src, dst, total);
+    GCV_CHECK_HIP(hipGetLastError());
+    GCV_CHECK_HIP(hipDeviceSynchronize());
+    if (tmp) GCV_CHECK_HIP(hipFree(tmp));
+    return 0;
+  }
+
+  int load_vae(const TensorMap& w) override {
+    GCV_CHECK_HIP(hipSetDevice(device));
+    has_vae = false;
+    ws_vae.clear();
+    const int ech[5] = {3, 16, 32, 64, 128};
+    const int eidx[4] = {0, 3, 6, 9};
+    for (int l = 0; l < 4; ++l) {
+      const int c = ech[l + 1];
+      const std::string cn = "encoder.features." + std::to_string(eidx[l]);
+      const std::string bn = "encoder.features." + std::to_string(eidx[l] + 1);
+      std::vector<float> cb, g, be, rm, rv;
+      GCV_TRY(fetch(w, cn + ".bias", c, cb));
+      GCV_TRY(fetch(w, bn + ".weight", c, g));
+      GCV_TRY(fetch(w, bn + ".bias", c, be));
+      GCV_TRY(fetch(w, bn + ".running_mean", c, rm));
+      GCV_TRY(fetch(w, bn + ".running_var", c, rv));
+      // eval-mode BatchNorm2d (eps 1e-5) folded into the conv: y = conv(x)*s + (b - mean)*s + beta
+      std::vector<float> scale(c), bias(c);
+      for (int i = 0; i < c; ++i) {
+        scale[i] = g[i] / std::sqrt(rv[i] + 1e-5f);
+        bias[i] = (cb[i] - rm[i]) * scale[i] + be[i];
+      }
+      if (l == 0) {
+        GCV_TRY(up_conv_first(w, cn + ".weight", &scale, ws_vae, vae.enc1_w));
+        GCV_UP(vae.enc1_b, ws_vae, bias);
+      } else {
+        GCV_TRY(up_conv_gemm(w, cn + ".weight", c, ech[l], 3, 3, &scale, ws_vae, vae.enc_w[l - 1]));
+        GCV_UP(vae.enc_b[l - 1], ws_vae, bias);
+      }
+    }
+    GCV_TRY(pack_mu(w, "encoder.mu.weight", vae.mu_w));
+    GCV_TRY(up_f32(w, "encoder.mu.bias", 12544, ws_vae, vae.mu_b));
+    vae.var_w = nullptr;
+    vae.var_b = nullptr;
+    if (w.count("encoder.var.weight")) {     // only needed for the optional KL output
+      GCV_TRY(pack_mu(w, "encoder.var.weight", vae.var_w));
+      GCV_TRY(up_f32(w, "encoder.var.bias", 12544, ws_vae, vae.var_b));
+    }
+    const int dch[4] = {256, 64, 32, 16};
+    const int didx[3] = {0, 2, 4};
+    for (int l = 0; l < 3; ++l) {
+      const std::string n = "decoder.features." + std::to_string(didx[l]);
+      GCV_TRY(up_convt_gemm(w, n + ".weight", dch[l], dch[l + 1], ws_vae, vae.dec_w[l]));
+      GCV_TRY(up_f32(w, n + ".bias", dch[l + 1], ws_vae, vae.dec_b[l]));
+    }
+    GCV_TRY(up_convt_small(w, "decoder.features.6.weight", ws_vae, vae.dec4_w));
+    GCV_TRY(up_f32(w, "decoder.features.6.bias", 3, ws_vae, vae.dec4_b));
+    GCV_TRY(pack_convnext(w, "convnext_backbone.", ws_vae, bb_vae));
+    GCV_TRY(pack_head(w, ws_vae, vae.head));
+    has_vae = true;
+    return 0;
+  }
+
+  int load_swin(const TensorMap& w, const std::string& prefix) override {
+    GCV_CHECK_HIP(hipSetDevice(device));
+    has_swin = false;
+    ws_swin.clear();
+    GCV_TRY(pack_swin<T>(w, prefix, ws_swin, swin));
+    has_swin = true;
+    return 0;
+  }
+
+  // ------------------------------------------------------------ ConvNeXt-T over token segments
+  int run_convnext(const CnxW<T>& w, const Seg<T>* segs, int nseg) {
+    int h[4], wd[4];
+    int64_t m[4], moff[4], M = 0;
+    int ntot = 0;
+    GCV_REQUIRE(nseg >= 1 && nseg <= 4, "1..4 segments");
+    for (int s = 0; s < nseg; ++s) {
+      GCV_REQUIRE(segs[s].H % 4 == 0 && segs[s].W % 4 == 0 && segs[s].n > 0, "segment geometry");
+      h[s] = segs[s].H / 4;
+      wd[s] = segs[s].W / 4;
+      m[s] = (int64_t)segs[s].n * h[s] * wd[s];
+      moff[s] = M;
+      M += m[s];
+      ntot += segs[s].n;
+    }
+    GCV_REQUIRE(M * 384 < (int64_t)1 << 31, "token count too large for 32-bit GEMM indexing");
+    const size_t mk = arena.mark();
+    T* X = arena.get<T>(M * 96);
+    T* Y = arena.get<T>(M * 96);
+    T* Hd = arena.get<T>(M * 384);
+    T* Pool = arena.get<T>((int64_t)ntot * 768);
+    if (!arena.dry && arena.overflow) { set_error("workspace arena too small: batch exceeds max_batch"); return -6; }
+
+    for (int s = 0; s < nseg; ++s) {
+      const Seg<T>& g = segs[s];
+      GCV_TRY(run("cnx.stem_ln", 2.0 * m[s] * 96 * 48, sizeof(T) * (double)m[s] * (48 + 96), [&] {
+        return launch_stem_ln<T>(g.x, g.sb, g.sc, g.sy, g.sx, w.stem_w, w.stem_b, w.stem_lnw, w.stem_lnb,
+                                 X + moff[s] * 96, g.n, h[s], wd[s], 1e-6f, cur);
+      }));
+    }
+    int bi = 0;
+    for (int i = 0; i < 4; ++i) {
+      const int C = kDims[i];
+      if (i > 0) {
+        const int Cp = kDims[i - 1];
+        int64_t newM = 0, noff[4];
+        for (int s = 0; s < nseg; ++s) {
+          noff[s] = newM;
+          const int nh = h[s] / 2, nw = wd[s] / 2;
+          GCV_REQUIRE(nh > 0 && nw > 0, "image too small for ConvNeXt downsampling");
+          GCV_TRY(run("cnx.ln_patchify", 8.0 * m[s] * Cp, 2.0 * sizeof(T) * (double)m[s] * Cp, [&] {
+            return launch_ln_patchify<T>(X + moff[s] * Cp, w.down[i - 1].ln_w, w.down[i - 1].ln_b,
+                                         Y + noff[s] * 4 * Cp, segs[s].n, h[s], wd[s], Cp, 1e-6f, cur);
+          }));
+          newM += (int64_t)segs[s].n * nh * nw;
+        }
+        for (int s = 0; s < nseg; ++s) {
+          h[s] /= 2;
+          wd[s] /= 2;
+          m[s] = (int64_t)segs[s].n * h[s] * wd[s];
+          moff[s] = noff[s];
+        }
+        M = newM;
+        GemmArgs g{};
+        g.A = Y; g.lda = 4 * Cp; g.Wt = w.down[i - 1].w; g.C = X; g.ldc = C; g.bias = w.down[i - 1].b;
+        g.M = (int)M; g.N = C; g.K = 4 * Cp; g.act = ACT_NONE; g.splitk = 1;
+        GCV_TRY(gemm("cnx.down_gemm", g, A_PLAIN, EPI_BIAS_ACT));
+      }
+      for (int j = 0; j < kDepths[i]; ++j, ++bi) {
+        const CnxBlockW<T>& k = w.blk[bi];
+        for (int s = 0; s < nseg; ++s) {
+          GCV_TRY(run("cnx.dwconv7_ln", 2.0 * 49 * m[s] * C, 2.0 * sizeof(T) * (double)m[s] * C + 49.0 * C * 4, [&] {
+            return launch_dwconv7_ln<T>(X + moff[s] * C, k.dw_w, k.dw_b, k.ln_w, k.ln_b, Y + moff[s] * C, segs[s].n,
+                                        h[s], wd[s], C, 1e-6f, cur);
+          }));
+        }
+        GemmArgs g1{};
+        g1.A = Y; g1.lda = C; g1.Wt = k.fc1_w; g1.C = Hd; g1.ldc = 4 * C; g1.bias = k.fc1_b;
+        g1.M = (int)M; g1.N = 4 * C; g1.K = C; g1.act = ACT_GELU; g1.splitk = 1;
+        GCV_TRY(gemm("cnx.pw1_gelu", g1, A_PLAIN, EPI_BIAS_ACT));
+        GemmArgs g2{};
+        g2.A = Hd; g2.lda = 4 * C; g2.Wt = k.fc2_w; g2.C = X; g2.ldc = C; g2.bias = k.fc2_b; g2.gamma = k.gamma;
+        g2.resid = X; g2.M = (int)M; g2.N = C; g2.K = 4 * C; g2.act = ACT_NONE; g2.splitk = 1;
+        GCV_TRY(gemm("cnx.pw2_scale_res", g2, A_PLAIN, EPI_RESID));
+      }
+    }
+    int no = 0;
+    for (int s = 0; s < nseg; ++s) {
+      const int HW = h[s] * wd[s];
+      GCV_TRY(run("cnx.pool_ln", 2.0 * m[s] * 768, sizeof(T) * (double)m[s] * 768, [&] {
+        return launch_pool_ln<T>(X + moff[s] * 768, w.head_lnw, w.head_lnb, Pool + (int64_t)no * 768, segs[s].n, HW,
+                                 768, 1e-6f, cur);
+      }));
+      GemmArgs g{};
+      g.A = Pool + (int64_t)no * 768; g.lda = 768; g.Wt = w.head_fc_w; g.C = segs[s].out; g.ldc = segs[s].out_ld;
+      g.bias = w.head_fc_b; g.M = segs[s].n; g.N = 1000; g.K = 768; g.act = segs[s].act; g.splitk = 1;
+      GCV_TRY(gemm("cnx.head_fc", g, A_PLAIN, EPI_BIAS_ACT));
+      no += segs[s].n;
+    }
+    arena.release(mk);
+    return 0;
+  }
+
+  int run_head(const HeadW<T>& hw, const T* feat, int B, int act, float* logits) {
+    const size_t mk = arena.mark();
+    T* hbuf = arena.get<T>((int64_t)B * 500 + 8);
+    GemmArgs g{};
+    g.A = feat; g.lda = 2000; g.Wt = hw.fc_w; g.C = hbuf; g.ldc = 500; g.bias = hw.fc_b;
+    g.M = B; g.N = 500; g.K = 2000; g.act = act; g.splitk = 1;
+    GCV_TRY(gemm("head.fc", g, A_PLAIN, EPI_BIAS_ACT));
+    GCV_TRY(run("head.fc2", 2.0 * B * 2 * 500, sizeof(T) * (double)B * 500,
+                [&] { return launch_head_tail<T>(hbuf, hw.fc2_w, hw.fc2_b, logits, B, 500, cur); }));
+    arena.release(mk);
+    return 0;
+  }
+
+  int check_batch(int B) {
+    GCV_REQUIRE(B >= 1, "batch must be >= 1");
+    GCV_REQUIRE(B <= max_batch, "batch exceeds the max_batch this handle was created with");
+    return 0;
+  }
+
+  // ------------------------------------------------------------ ED (model/genconvit_ed.py:77-88)
+  int ed_forward(const void* xv, int B, float* logits, hipStream_t s) override {
+    if (!arena.dry) {
+      GCV_REQUIRE(has_ed, "ED weights not loaded (gcv_load_ed)");
+      GCV_TRY(check_batch(B));
+      GCV_REQUIRE(xv && logits, "null input/output");
+    }
+    cur = s;
+    const T* x = (const T*)xv;
+    const size_t mk = arena.mark();
+    T* e1 = arena.get<T>((int64_t)B * 112 * 112 * 16);
+    T* e2 = arena.get<T>((int64_t)B * 56 * 56 * 32);
+    T* e3 = arena.get<T>((int64_t)B * 28 * 28 * 64);
+    T* e4 = arena.get<T>((int64_t)B * 14 * 14 * 128);
+    T* e5 = arena.get<T>((int64_t)B * 7 * 7 * 256);
+    T* d1 = arena.get<T>((int64_t)B * 14 * 14 * 128);
+    T* d2 = arena.get<T>((int64_t)B * 28 * 28 * 64);
+    T* d3 = arena.get<T>((int64_t)B * 56 * 56 * 32);
+    T* d4 = arena.get<T>((int64_t)B * 112 * 112 * 16);
+    T* rec = arena.get<T>((int64_t)B * 224 * 224 * 3);
+    T* feat = arena.get<T>((int64_t)B * 2000);
+    if (!arena.dry && arena.overflow) { set_error("workspace arena too small"); return -6; }
+
+    GCV_TRY(run("ed.enc1_conv3_relu_pool", 2.0 * B * 224 * 224 * 16 * 27,
+                sizeof(T) * (double)B * (3 * 224 * 224 + 16 * 112 * 112), [&] {
+      return launch_conv3_first<T>(x, 3 * 224 * 224, 224 * 224, 224, 1, ed.enc1_w, ed.enc1_b, e1, B, 224, 224, true,
+                                   ACT_RELU, cur);
+    }));
+    {
+      const T* in[4] = {e1, e2, e3, e4};
+      T* out[4] = {e2, e3, e4, e5};
+      const int Hs[4] = {112, 56, 28, 14};
+      const int cl[4] = {4, 5, 6, 7};
+      for (int l = 0; l < 4; ++l) {
+        GemmArgs g{};
+        g.A = in[l]; g.Wt = ed.enc_w[l]; g.C = out[l]; g.bias = ed.enc_b[l];
+        g.M = B * Hs[l] * Hs[l]; g.N = 2 << cl[l]; g.K = 9 << cl[l]; g.ldc = g.N; g.act = ACT_RELU; g.splitk = 1;
+        g.H = Hs[l]; g.W = Hs[l]; g.cin_log2 = cl[l];
+        GCV_TRY(gemm("ed.enc_conv3_relu_pool", g, A_IM2COL3_POOL, EPI_POOL4));
+      }
+    }
+    {
+      const T* in[4] = {e5, d1, d2, d3};
+      T* out[4] = {d1, d2, d3, d4};
+      const int Hs[4] = {7, 14, 28, 56};
+      const int col[4] = {7, 6, 5, 4};   // log2(Cout)
+      for (int l = 0; l < 4; ++l) {
+        GemmArgs g{};
+        g.A = in[l]; g.lda = 2 << col[l]; g.Wt = ed.dec_w[l]; g.C = out[l]; g.bias = ed.dec_b[l];
+        g.M = B * Hs[l] * Hs[l]; g.N = 4 << col[l]; g.K = 2 << col[l]; g.act = ACT_RELU; g.splitk = 1;
+        g.H = Hs[l]; g.W = Hs[l]; g.cout_log2 = col[l];
+        GCV_TRY(gemm("ed.dec_convT_relu", g, A_PLAIN, EPI_CONVT));
+      }
+    }
+    GCV_TRY(run("ed.dec5_convT_relu", 2.0 * B * 112 * 112 * 16 * 12,
+                sizeof(T) * (double)B * (16 * 112 * 112 + 3 * 224 * 224),
+                [&] { return launch_convt2_small<T>(d4, ed.dec5_w, ed.dec5_b, rec, B, 112, 112, ACT_RELU, cur); }));
+    // both backbone passes share weights and shape -> one 2B-image token stream.
+    // cat order (genconvit_ed.py:85): [backbone(recon), backbone(orig)], activation GELU (:75)
+    Seg<T> segs[2];
+    segs[0] = Seg<T>{rec, (int64_t)224 * 224 * 3, 1, 224 * 3, 3, B, 224, 224, feat, 2000, ACT_GELU};
+    segs[1] = Seg<T>{x, (int64_t)3 * 224 * 224, 224 * 224, 224, 1, B, 224, 224, feat + 1000, 2000, ACT_GELU};
+    GCV_TRY(run_convnext(bb_ed, segs, 2));
+    GCV_TRY(run_head(ed.head, feat, B, ACT_GELU, logits));
+    arena.release(mk);
+    return 0;
+  }
+
+  // ------------------------------------------------------------ VAE (model/genconvit_vae.py:107-116)
+  int vae_forward(const void* xv, const float* eps, int B, float* logits, void* recon224, float* mse, float* kl,
+                  hipStream_t s) override {
+    if (!arena.dry) {
+      GCV_REQUIRE(has_vae, "VAE weights not loaded (gcv_load_vae)");
+      GCV_TRY(check_batch(B));
+      GCV_REQUIRE(xv && eps && logits, "null input/eps/output");
+      GCV_REQUIRE(!kl || vae.var_w, "KL requested but encoder.var weights were not loaded");
+    }
+    cur = s;
+    const T* x = (const T*)xv;
+    const int SPLITK = 8, KPS = 25088 / 8;     // 3136 = 49*64
+    const size_t mk = arena.mark();
+    T* v1 = arena.get<T>((int64_t)B * 112 * 112 * 16);
+    T* v2 = arena.get<T>((int64_t)B * 56 * 56 * 32);
+    T* v3 = arena.get<T>((int64_t)B * 28 * 28 * 64);
+    T* v4 = arena.get<T>((int64_t)B * 14 * 14 * 128);
+    float* part = arena.get<float>((int64_t)SPLITK * B * 12544);
+    float* mu = arena.get<float>((int64_t)B * 12544);
+    float* rowsum = arena.get<float>(B + 8);
+    T* z = arena.get<T>((int64_t)B * 12544);
+    T* d1 = arena.get<T>((int64_t)B * 14 * 14 * 64);
+    T* d2 = arena.get<T>((int64_t)B * 28 * 28 * 32);
+    T* d3 = arena.get<T>((int64_t)B * 56 * 56 * 16);
+    T* xhat = arena.get<T>((int64_t)B * 112 * 112 * 3);
+    T* feat = arena.get<T>((int64_t)B * 2000);
+    float* msepart = arena.get<float>((int64_t)B * 196);
+    if (!arena.dry && arena.overflow) { set_error("workspace arena too small"); return -6; }
+
+    GCV_TRY(run("vae.enc1_conv3s2_bn_leaky", 2.0 * B * 112 * 112 * 16 * 27,
+                sizeof(T) * (double)B * (3 * 224 * 224 + 16 * 112 * 112), [&] {
+      return launch_conv3_first<T>(x, 3 * 224 * 224, 224 * 224, 224, 1, vae.enc1_w, vae.enc1_b, v1, B, 224, 224,
+                                   false, ACT_LEAKY, cur);
+    }));
+    {
+      const T* in[3] = {v1, v2, v3};
+      T* out[3] = {v2, v3, v4};
+      const int Hs[3] = {112, 56, 28};
+      const int cl[3] = {4, 5, 6};
+      for (int l = 0; l < 3; ++l) {
+        GemmArgs g{};
+        g.A = in[l]; g.Wt = vae.enc_w[l]; g.C = out[l]; g.bias = vae.enc_b[l];
+        g.M = B * (Hs[l] / 2) * (Hs[l] / 2); g.N = 2 << cl[l]; g.K = 9 << cl[l]; g.ldc = g.N; g.act = ACT_LEAKY;
+        g.splitk = 1; g.H = Hs[l]; g.W = Hs[l]; g.cin_log2 = cl[l];
+        GCV_TRY(gemm("vae.enc_conv3s2_bn_leaky", g, A_IM2COL3_S2, EPI_BIAS_ACT));
+      }
+    }
+    {
+      GemmArgs g{};
+      g.A = v4; g.lda = 25088; g.Wt = vae.mu_w; g.partial = part; g.M = B; g.N = 12544; g.K = 25088;
+      g.splitk = SPLITK; g.k_per_split = KPS; g.act = ACT_NONE;
+      GCV_TRY(gemm("vae.mu_gemm_splitk", g, A_PLAIN, EPI_SPLITK));
+      GCV_TRY(run("vae.reparam", 4.0 * B * 12544, 4.0 * (SPLITK + 2) * (double)B * 12544, [&] {
+        return launch_reparam<T>(part, SPLITK, vae.mu_b, eps, mu, z, B, 12544, cur);
+      }));
+      if (kl) {
+        g.Wt = vae.var_w;
+        GCV_TRY(gemm("vae.var_gemm_splitk", g, A_PLAIN, EPI_SPLITK));
+        GCV_TRY(run("vae.kl", 6.0 * B * 12544, 4.0 * (SPLITK + 1) * (double)B * 12544,
+                    [&] { return launch_kl(part, SPLITK, vae.var_b, mu, rowsum, kl, B, 12544, cur); }));
+      }
+    }
+    {
+      const T* in[3] = {z, d1, d2};
+      T* out[3] = {d1, d2, d3};
+      const int Hs[3] = {7, 14, 28};
+      const int cin[3] = {256, 64, 32};
+      const int col[3] = {6, 5, 4};
+      for (int l = 0; l < 3; ++l) {
+        GemmArgs g{};
+        g.A = in[l]; g.lda = cin[l]; g.Wt = vae.dec_w[l]; g.C = out[l]; g.bias = vae.dec_b[l];
+        g.M = B * Hs[l] * Hs[l]; g.N = 4 << col[l]; g.K = cin[l]; g.act = ACT_LEAKY; g.splitk = 1;
+        g.H = Hs[l]; g.W = Hs[l]; g.cout_log2 = col[l];
+        GCV_TRY(gemm("vae.dec_convT_leaky", g, A_PLAIN, EPI_CONVT));
+      }
+    }
+    GCV_TRY(run("vae.dec4_convT_leaky", 2.0 * B * 56 * 56 * 16 * 12,
+                sizeof(T) * (double)B * (16 * 56 * 56 + 3 * 112 * 112),
+                [&] { return launch_convt2_small<T>(d3, vae.dec4_w, vae.dec4_b, xhat, B, 56, 56, ACT_LEAKY, cur); }));
+    // cat order (genconvit_vae.py:113): [backbone(x @224), backbone(x_hat @112)], activation ReLU (:104)
+    Seg<T> segs[2];
+    segs[0] = Seg<T>{x, (int64_t)3 * 224 * 224, 224 * 224, 224, 1, B, 224, 224, feat, 2000, ACT_RELU};
+    segs[1] = Seg<T>{xhat, (int64_t)112 * 112 * 3, 1, 112 * 3, 3, B, 112, 112, feat + 1000, 2000, ACT_RELU};
+    GCV_TRY(run_convnext(bb_vae, segs, 2));
+    GCV_TRY(run_head(vae.head, feat, B, ACT_RELU, logits));
+    if (recon224 || mse) {
+      GCV_TRY(run("vae.resize_mse", 30.0 * B * 224 * 224, sizeof(T) * (double)B * (3 * 112 * 112 + 6 * 224 * 224), [&] {
+        return launch_resize_mse<T>(xhat, x, (T*)recon224, msepart, mse, B, cur);
+      }));
+    }
+    arena.release(mk);
+    return 0;
+  }
+
+  // standalone backbone pass (unit parity / A5): x NCHW (B,3,res,res) -> (B,1000) in T
+  int convnext_forward(int which, const void* xv, int B, int res, void* logits1000, hipStream_t s) override {
+    GCV_REQUIRE(which == 0 ? has_ed : has_vae, "backbone weights not loaded");
+    GCV_TRY(check_batch(B));
+    GCV_REQUIRE(res % 4 == 0 && res >= 32 && res <= 224, "resolution must be a multiple of 4 in [32,224]");
+    cur = s;
+    Seg<T> seg{(const T*)xv, (int64_t)3 * res * res, (int64_t)res * res, res, 1, B, res, res, (T*)logits1000, 1000, ACT_NONE};
+    return run_convnext(which == 0 ? bb_ed : bb_vae, &seg, 1);
+  }
+
+  int swin_forward(const void* xv, int B, void* logits1000, hipStream_t s) override {
+    if (!arena.dry) {
+      GCV_REQUIRE(has_swin, "Swin weights not loaded (gcv_load_swin)");
+      GCV_TRY(check_batch(B));
+    }
+    cur = s;
+    return run_swin<T>(*this, swin, (const T*)xv, B, (T*)logits1000);
+  }
+
+  int init() override {
+    GCV_CHECK_HIP(hipSetDevice(device));
+    arena.dry = true;
+    arena.off = arena.peak = 0;
+    int rc = ed_forward(nullptr, max_batch, nullptr, nullptr);
+    if (!rc) rc = vae_forward(nullptr, nullptr, max_batch, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (!rc) rc = swin_forward(nullptr, max_batch, nullptr, nullptr);
+    arena.dry = false;
+    if (rc) return rc;
+    arena.cap = arena.peak + 4096;
+    arena.off = 0;
+    GCV_CHECK_HIP(hipMalloc((void**)&arena.base, arena.cap));
+    return 0;
+  }
+};
+
+}  // namespace gcv

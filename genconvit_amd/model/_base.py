@@ -1,0 +1,103 @@
+"""Shared plumbing of the HIP-backed GenConViT modules: reference-named parameters held as ordinary
+``nn.Parameter``s (so ``state_dict`` / ``load_state_dict`` / ``.to()`` / ``.half()`` / ``.parameters()``
+behave like the reference's modules), plus a lazily (re)built :class:`genconvit_amd._lib.Handle`
+that owns the packed device copy the kernels read.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import _lib, synth
+
+
+def build_param_tree(root: nn.Module, entries, init: str, seed: int, tag: str):
+    """Register ``entries`` (name, shape, kind) under ``root`` with dotted names -> nested modules,
+    so ``root.state_dict()`` has exactly the reference's keys."""
+    for name, shape, kind in entries:
+        parts = name.split(".")
+        node = root
+        for p in parts[:-1]:
+            if p not in node._modules:
+                node.add_module(p, nn.Module())
+            node = node._modules[p]
+        if init == "synthetic":
+            t = synth.make_param(tag + name, shape, kind, seed)
+        elif init == "empty":
+            t = torch.zeros(shape) if kind in ("bn_mean",) else torch.ones(shape) if kind == "bn_var" else torch.empty(shape)
+        else:
+            raise ValueError(f"init must be 'synthetic' or 'empty', got {init!r}")
+        if kind in ("bn_mean", "bn_var"):
+            node.register_buffer(parts[-1], t)
+        else:
+            node.register_parameter(parts[-1], nn.Parameter(t, requires_grad=False))
+
+
+# state_dict keys of the published checkpoints that never take part in forward (SURVEY.md §0.4,
+# Appendix A.3): the Swin "embedder" (registered twice) and HybridEmbed.proj, BN counters.
+OFF_PATH_MARKERS = ("embedder.", "patch_embed.", "num_batches_tracked")
+
+
+class HipModule(nn.Module):
+    """Base class: parameter tree + handle lifecycle."""
+
+    _default_max_batch = 32
+
+    def __init__(self):
+        super().__init__()
+        self._handle = None
+        self._handle_key = None
+        self._dirty = True
+        self._max_batch = self._default_max_batch
+
+    # nn.Module._apply is what .to()/.half()/.float()/.cuda() go through
+    def _apply(self, fn, *a, **k):
+        self._dirty = True
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        own = set(self.state_dict().keys())
+        filtered = {k: v for k, v in state_dict.items()
+                    if k in own or not any(m in k for m in OFF_PATH_MARKERS)}
+        self._dirty = True
+        return super().load_state_dict(filtered, strict=strict, **kw)
+
+    def _param_device_dtype(self):
+        p = next(self.parameters())
+        return p.device, p.dtype
+
+    def _load_into(self, handle):   # subclasses push their weights
+        raise NotImplementedError
+
+    def _get_handle(self, batch: int):
+        device, dtype = self._param_device_dtype()
+        if device.type != "cuda":
+            raise _lib.GenConViTHipError(
+                "model parameters are on CPU: the GenConViT HIP path has no CPU fallback — call .to('cuda') "
+                "on a machine with an MI355X")
+        if batch > self._max_batch:
+            self._max_batch = 1 << (batch - 1).bit_length()
+        key = (device.index if device.index is not None else torch.cuda.current_device(), dtype, self._max_batch)
+        if self._handle is None or self._handle_key != key:
+            if self._handle is not None:
+                self._handle.close()
+            self._handle = _lib.Handle(key[0], dtype, self._max_batch)
+            self._handle_key = key
+            self._dirty = True
+        if self._dirty:
+            self._load_into(self._handle)
+            self._dirty = False
+        return self._handle
+
+    def reserve(self, max_batch: int):
+        """Size the workspace for batches up to ``max_batch`` ahead of the first call."""
+        self._max_batch = max(int(max_batch), 1)
+        return self
+
+    def _prep_input(self, x):
+        device, dtype = self._param_device_dtype()
+        if x.device != device:
+            x = x.to(device)
+        if x.dtype != dtype:      # reference bug (prediction.py:248-249: df.half() result dropped) fixed here
+            x = x.to(dtype)
+        return x.contiguous()

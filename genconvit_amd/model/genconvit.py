@@ -1,0 +1,72 @@
+"""GenConViT ensemble wrapper — mirror of the reference's ``model/genconvit.py:7-75``.
+
+Same constructor ``GenConViT(config, ed, vae, net, fp16)``, same weight-file convention
+(``weight/{name}.pth`` relative to the cwd, raw state_dict or ``{'state_dict': ...}``), same error
+text when a file is missing, same forward: ``'ed'`` -> (B,2), ``'vae'`` -> (B,2), anything else ->
+``cat((ed, vae), dim=0)`` -> (2B,2).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+
+from .genconvit_ed import GenConViTED
+from .genconvit_vae import GenConViTVAE
+
+
+def _read_checkpoint(name):
+    path = name if os.path.isabs(name) or name.endswith(".pth") else os.path.join("weight", f"{name}.pth")
+    ckpt = torch.load(path, map_location=torch.device("cpu"))
+    return ckpt["state_dict"] if isinstance(ckpt, dict) and "state_dict" in ckpt else ckpt
+
+
+class GenConViT(nn.Module):
+    def __init__(self, config, ed, vae, net, fp16):
+        super().__init__()
+        self.net = net
+        self.fp16 = fp16
+        want_ed = net != "vae"
+        want_vae = net != "ed"
+        try:
+            if want_ed:
+                self.model_ed = GenConViTED(config, init="empty")
+                self.model_ed.load_state_dict(_read_checkpoint(ed))
+                self.model_ed.eval()
+            if want_vae:
+                self.model_vae = GenConViTVAE(config, init="empty")
+                self.model_vae.load_state_dict(_read_checkpoint(vae))
+                self.model_vae.eval()
+        except FileNotFoundError:
+            if net == "ed":
+                raise Exception(f"Error: weight/{ed}.pth file not found.")
+            if net == "vae":
+                raise Exception(f"Error: weight/{vae}.pth file not found.")
+            raise Exception("Error: Model weights file not found.")
+        if self.fp16:
+            self.half()
+
+    @classmethod
+    def from_modules(cls, model_ed=None, model_vae=None, net="genconvit", fp16=False):
+        """Build the wrapper around already constructed networks (synthetic weights, tests, bench)."""
+        self = cls.__new__(cls)
+        nn.Module.__init__(self)
+        self.net, self.fp16 = net, fp16
+        if net != "vae":
+            self.model_ed = model_ed
+        if net != "ed":
+            self.model_vae = model_vae
+        if fp16:
+            self.half()
+        return self
+
+    @torch.no_grad()
+    def forward(self, x, eps=None):
+        if self.net == "ed":
+            return self.model_ed(x)
+        if self.net == "vae":
+            return self.model_vae(x, eps=eps, want_recon=False)[0]
+        x1 = self.model_ed(x)
+        x2 = self.model_vae(x, eps=eps, want_recon=False)[0]
+        return torch.cat((x1, x2), dim=0)

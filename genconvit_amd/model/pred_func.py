@@ -1,0 +1,123 @@
+"""Inference API — mirror of the reference's ``model/pred_func.py:18-184`` for the hot path.
+
+Same names and argument meaning (``load_genconvit``, ``preprocess_frame``, ``pred_vid``,
+``max_prediction_value``, ``real_or_fake``, ``df_face``, ``face_rec``, ``extract_frames``,
+``is_video``, ``set_result``, ``store_result``).  ``prediction.py`` star-imports this module and
+relies on ``torch``/``os``/``np`` coming along, so they stay module globals.  The heavy CPU-side
+dependencies (cv2, dlib, face_recognition, decord) are imported lazily inside the video / face
+functions so the model path imports on a box without them.
+"""
+import os
+
+import numpy as np
+import torch
+
+from .. import _lib, synth
+from .config import load_config
+from .genconvit import GenConViT
+
+device = "cuda" if torch.cuda.is_available() else "cpu"
+
+
+def load_genconvit(config, net, ed_weight, vae_weight, fp16, arch_type="original", use_attention=True,
+                   use_residual=True):
+    """reference model/pred_func.py:18-64.  ``arch_type='v2'`` (an experiment fork with a different,
+    incompatible architecture) is out of scope of this build and rejected explicitly."""
+    device_str = "cuda" if torch.cuda.is_available() else "cpu"
+    print(f"Using device: {device_str}")
+    if arch_type == "v2":
+        raise NotImplementedError("GenConViTV2 is an experiment fork outside this build's scope (SURVEY.md §2 #9)")
+    model = GenConViT(config, ed=ed_weight, vae=vae_weight, net=net, fp16=fp16)
+    model.to(device)
+    model.eval()
+    if fp16:
+        model.half()
+    return model
+
+
+_MEAN = torch.tensor(synth.IMAGENET_MEAN, dtype=torch.float32).view(1, 3, 1, 1)
+_STD = torch.tensor(synth.IMAGENET_STD, dtype=torch.float32).view(1, 3, 1, 1)
+
+
+def preprocess_frame(frame):
+    """uint8 (N,224,224,3) -> normalised fp32 NCHW (reference :95-108 with the 'vid' transform of
+    dataset/loader.py:63-65,77), vectorised over the batch instead of a per-frame Python loop."""
+    df_tensor = torch.as_tensor(np.asarray(frame)).float().permute((0, 3, 1, 2)) / 255.0
+    df_tensor = (df_tensor - _MEAN) / _STD
+    if torch.cuda.is_available():
+        df_tensor = df_tensor.to(device)
+    return df_tensor
+
+
+def pred_vid(df, model):
+    """reference :111-120: sigmoid over logits, mean over rows, argmax."""
+    with torch.no_grad():
+        p = next(model.parameters())
+        if df.device != p.device:
+            df = df.to(p.device)
+        return max_prediction_value(torch.sigmoid(model(df).squeeze()))
+
+
+def max_prediction_value(y_pred):
+    """reference :123-131 (the device-side reduction is ``genconvit_amd._lib.vote``)."""
+    mean_val = torch.mean(y_pred, dim=0)
+    return (
+        torch.argmax(mean_val).item(),
+        mean_val[0].item() if mean_val[0] > mean_val[1] else abs(1 - mean_val[1]).item(),
+    )
+
+
+def real_or_fake(prediction):
+    return {0: "REAL", 1: "FAKE"}[prediction ^ 1]
+
+
+def extract_frames(video_file, frames_nums=15):
+    from decord import VideoReader, cpu
+    vr = VideoReader(video_file, ctx=cpu(0))
+    step_size = max(1, len(vr) // frames_nums)
+    return vr.get_batch(list(range(0, len(vr), step_size))[:frames_nums]).asnumpy()
+
+
+def face_rec(frames, p=None, klass=None):
+    import cv2
+    import dlib
+    import face_recognition
+    temp_face = np.zeros((len(frames), 224, 224, 3), dtype=np.uint8)
+    count = 0
+    mod = "cnn" if dlib.DLIB_USE_CUDA else "hog"
+    for frame in frames:
+        frame = cv2.cvtColor(frame, cv2.COLOR_RGB2BGR)
+        for (top, right, bottom, left) in face_recognition.face_locations(frame, number_of_times_to_upsample=0, model=mod):
+            if count >= len(frames):
+                break
+            face_image = cv2.resize(frame[top:bottom, left:right], (224, 224), interpolation=cv2.INTER_AREA)
+            temp_face[count] = cv2.cvtColor(face_image, cv2.COLOR_BGR2RGB)
+            count += 1
+    return ([], 0) if count == 0 else (temp_face[:count], count)
+
+
+def df_face(vid, num_frames, net):
+    img = extract_frames(vid, num_frames)
+    face, count = face_rec(img)
+    return preprocess_frame(face) if count > 0 else []
+
+
+def is_video(vid):
+    return os.path.isfile(vid) and vid.endswith((".avi", ".mp4", ".mpg", ".mpeg", ".mov"))
+
+
+def set_result():
+    return {"video": {"name": [], "pred": [], "klass": [], "pred_label": [], "correct_label": []}}
+
+
+def store_result(result, filename, y, y_val, klass, correct_label=None, compression=None):
+    v = result["video"]
+    v["name"].append(filename)
+    v["pred"].append(y_val)
+    v["klass"].append(klass.lower())
+    v["pred_label"].append(real_or_fake(y))
+    if correct_label is not None:
+        v["correct_label"].append(correct_label)
+    if compression is not None:
+        v["compression"].append(compression)
+    return result

@@ -1,0 +1,139 @@
+/* genconvit_hip.h — C ABI of libgenconvit_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for the GenConViT `ed` + `vae` inference forward.  The reference
+ * (ctxnn/GenConViT, pure PyTorch) has no FFI layer; each entry point below replaces the
+ * Python/ATen call it cites (paths relative to the reference root).  A maintainer binds
+ * these with ctypes/cffi exactly as genconvit_amd/_lib.py does.
+ *
+ * Conventions
+ *   - all pointers are device pointers (e.g. torch.Tensor.data_ptr()) unless stated otherwise
+ *   - `gcv_stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); work is enqueued,
+ *     never synchronised, by the forward calls
+ *   - return value 0 = ok; non-zero = error, text via gcv_last_error() (thread-local)
+ *   - a handle owns its packed weights + workspace; not thread-safe; one handle per stream
+ *   - frames: (B,3,224,224) NCHW contiguous in the handle's storage dtype, already normalised like
+ *     model/pred_func.py:95-108 (preprocess_frame); logits are always fp32 (B,2)
+ */
+#ifndef GENCONVIT_HIP_H
+#define GENCONVIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(GCV_BUILD)
+#pragma GCC visibility push(default)
+#endif
+
+typedef struct gcv_handle gcv_handle;
+typedef void* gcv_stream;
+
+enum { GCV_F32 = 0, GCV_BF16 = 1, GCV_F16 = 2 };               /* storage dtype of a handle      */
+enum { GCV_ACT_NONE = 0, GCV_ACT_RELU = 1, GCV_ACT_GELU = 2, GCV_ACT_LEAKY = 3 };
+
+/* One named fp32 tensor of a reference state_dict (key names as in weight/{ed,vae}.pth,
+ * SURVEY.md Appendix A.3).  `data` may be host or device memory. */
+typedef struct {
+  const char* name;
+  const void* data;     /* fp32, contiguous */
+  int64_t numel;
+  int on_device;
+} gcv_tensor_desc;
+
+const char* gcv_last_error(void);
+
+/* Handle lifetime.  Replaces GenConViT.__init__'s module construction + .to(device)/.half()
+ * (model/genconvit.py:9-64, model/pred_func.py:50-62).  `max_batch` sizes the workspace arena. */
+int  gcv_create(gcv_handle** h, int device, int dtype, int max_batch);
+void gcv_destroy(gcv_handle* h);
+size_t gcv_workspace_bytes(const gcv_handle* h);
+
+/* Weight loading: replaces load_state_dict of GenConViTED / GenConViTVAE
+ * (model/genconvit.py:16-21,30-35,47-56).  Tensors are re-packed once (conv weights to GEMM
+ * order, BatchNorm folded, mu/var columns permuted to NHWC, cast to the handle dtype).
+ * Keys that never run in forward (embedder.*, *.patch_embed.*, encoder.fc1/fc2, fc3,
+ * num_batches_tracked) are ignored; a missing on-path key is an error. */
+int gcv_load_ed (gcv_handle* h, const gcv_tensor_desc* w, int n);
+int gcv_load_vae(gcv_handle* h, const gcv_tensor_desc* w, int n);
+/* Swin-T embedder weights (timm swin_tiny_patch4_window7_224 keys under `prefix`, e.g. "embedder.");
+ * constructed-but-never-executed in the reference forward (model/genconvit_ed.py:69-70). */
+int gcv_load_swin(gcv_handle* h, const gcv_tensor_desc* w, int n, const char* prefix);
+
+/* GenConViTED.forward (model/genconvit_ed.py:77-88): logits[b] = fc2(gelu(fc(gelu(cat(
+ * backbone(decoder(encoder(x))), backbone(x)))))). */
+int gcv_ed_forward(gcv_handle* h, const void* x_nchw, int batch, float* logits, gcv_stream stream);
+
+/* GenConViTVAE.forward (model/genconvit_vae.py:107-116) with the encoder's single
+ * torch.randn_like draw (model/genconvit_vae.py:46) made an explicit fp32 input `eps` (B,12544).
+ *   recon224 : nullable, (B,3,224,224) in the handle dtype = transforms.Resize((224,224))(x_hat) (:116)
+ *   mse      : nullable, (B) fp32 per-frame mean((recon224 - x)^2); its mean is the reference's
+ *              nn.MSELoss()(recons, images) (train/train_vae.py:24,76)
+ *   kl       : nullable, (1) fp32 = Encoder.kl (model/genconvit_vae.py:58) */
+int gcv_vae_forward(gcv_handle* h, const void* x_nchw, const float* eps, int batch, float* logits,
+                    void* recon224, float* mse, float* kl, gcv_stream stream);
+
+/* timm convnext_tiny forward alone (call sites model/genconvit_ed.py:82-83,
+ * model/genconvit_vae.py:111-112): which = 0 the ED backbone, 1 the VAE backbone;
+ * x (B,3,res,res) -> logits1000 (B,1000) in the handle dtype. */
+int gcv_convnext_forward(gcv_handle* h, int which, const void* x_nchw, int batch, int res,
+                         void* logits1000, gcv_stream stream);
+
+/* timm swin_tiny_patch4_window7_224 forward (only executed by HybridEmbed.__init__,
+ * model/model_embedder.py:22): x (B,3,224,224) -> (B,1000) in the handle dtype. */
+int gcv_swin_forward(gcv_handle* h, const void* x_nchw, int batch, void* logits1000, gcv_stream stream);
+
+/* pred_vid's reduction (model/pred_func.py:120,125): mean2[c] = mean_r sigmoid(logits[r][c]). */
+int gcv_vote(const float* logits, int rows, float* mean2, gcv_stream stream);
+
+/* Per-launch timing with HIP events on the launch stream.  After gcv_profile_enable(h,1) every
+ * kernel launch of the following forwards is bracketed by events; gcv_profile_report() waits for
+ * them and returns a JSON array aggregated by op tag (launches, ms, algorithmic flops / bytes)
+ * and clears the records.  The returned string lives until the next call on the handle. */
+int gcv_profile_enable(gcv_handle* h, int on);
+const char* gcv_profile_report(gcv_handle* h);
+
+/* ---- per-kernel entry points (unit parity tests; same kernels the forwards launch) ---- */
+enum { GCV_A_PLAIN = 0, GCV_A_IM2COL3_POOL = 1, GCV_A_IM2COL3_S2 = 2 };
+enum { GCV_EPI_BIAS_ACT = 0, GCV_EPI_RESID = 1, GCV_EPI_POOL4 = 2, GCV_EPI_CONVT = 3, GCV_EPI_SPLITK = 4 };
+
+typedef struct {
+  const void* A; const void* Wt; void* C;
+  const float* bias; const float* gamma; const void* resid; float* partial;
+  int M, N, K, lda, ldc, act, splitk, k_per_split, H, W, cin_log2, cout_log2;
+} gcv_gemm_args;
+
+/* C = epilogue(A * Wt^T): nn.Linear / Conv2d-as-GEMM / ConvTranspose2d(k=s=2) / split-K slab */
+int gcv_k_gemm(int dtype, int a_mode, int epi, const gcv_gemm_args* a, gcv_stream s);
+int gcv_k_stem_ln(int dtype, const void* x, int64_t sb, int64_t sc, int64_t sy, int64_t sx, const float* wp,
+                  const float* bias, const float* lnw, const float* lnb, void* out, int nimg, int Ho, int Wo,
+                  float eps, gcv_stream s);
+int gcv_k_dwconv7_ln(int dtype, const void* x, const float* wdw, const float* bdw, const float* lnw,
+                     const float* lnb, void* y, int nimg, int H, int W, int C, float eps, gcv_stream s);
+int gcv_k_ln_patchify(int dtype, const void* x, const float* w, const float* b, void* out, int nimg, int H, int W,
+                      int C, float eps, gcv_stream s);
+int gcv_k_layernorm_rows(int dtype, const void* x, const float* w, const float* b, void* out, int64_t rows, int C,
+                         float eps, gcv_stream s);
+int gcv_k_pool_ln(int dtype, const void* x, const float* w, const float* b, void* out, int nimg, int HW, int C,
+                  float eps, gcv_stream s);
+int gcv_k_conv3_first(int dtype, const void* x, int64_t sb, int64_t sc, int64_t sy, int64_t sx, const float* wp,
+                      const float* bias, void* out, int nimg, int H, int W, int pool, int act, gcv_stream s);
+int gcv_k_convt2_small(int dtype, const void* x, const float* wp, const float* bias, void* out, int nimg, int H,
+                       int W, int act, gcv_stream s);
+int gcv_k_reparam(int dtype, const float* partial, int splitk, const float* bias, const float* eps, float* mu_out,
+                  void* z_nhwc, int B, int N, gcv_stream s);
+int gcv_k_head_tail(int dtype, const void* h, const float* w, const float* bias, float* logits, int B, int K,
+                    gcv_stream s);
+int gcv_k_resize_mse(int dtype, const void* xhat, const void* img, void* recon, float* msepart, float* mse, int B,
+                     gcv_stream s);
+
+#if defined(GCV_BUILD)
+#pragma GCC visibility pop
+#endif
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENCONVIT_HIP_H */

@@ -1,0 +1,324 @@
+"""Per-kernel parity on the MI355X: every HIP kernel (called through the C ABI's gcv_k_* entry
+points) against a plain PyTorch fp32 CPU reference of the same op.  fp32 storage must agree to
+~1e-5; 16-bit storage is checked against the same fp32 math on inputs rounded to that dtype."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from genconvit_amd import _lib
+from tests import kutil
+from tests.kutil import DTYPES, dev, gemm, ptr, rnd, tol
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+ALL = ["f32", "bf16", "f16"]
+
+
+def q(t, dtype):
+    """round a fp32 CPU tensor through the storage dtype"""
+    return t.to(dtype).float()
+
+
+def act_ref(x, act):
+    return {0: lambda v: v, 1: F.relu, 2: F.gelu, 3: lambda v: F.leaky_relu(v, 0.01)}[act](x)
+
+
+def assert_close(got, want, atol, what=""):
+    err = (got.float().cpu() - want).abs().max().item()
+    assert err <= atol, f"{what}: max abs err {err:.3e} > {atol:.3e}"
+
+
+# ----------------------------------------------------------------------------- GEMM, plain A
+@pytest.mark.parametrize("dt", ALL)
+@pytest.mark.parametrize("M,N,K,act", [
+    (300, 384, 96, 2),      # 128x96 tiles, M tail, GELU (ConvNeXt pw1 shape class)
+    (200, 1000, 768, 0),    # 128x128 tiles with N tail (head fc)
+    (40, 500, 2000, 2),     # 64x128 tiles, N tail (GenConViT fc)
+    (8, 1000, 768, 1),      # 32x128 tiles
+    (130, 192, 1536, 0),    # downsample-conv shape class, long K
+    (256, 96, 48, 3),       # K shorter than one 16-bit K tile
+])
+def test_gemm_bias_act(dt, M, N, K, act):
+    dtype = DTYPES[dt]
+    A, W = q(rnd((M, K), 1), dtype), q(rnd((N, K), 2, 1 / math.sqrt(K)), dtype)
+    bias = rnd((N,), 3, 0.1)
+    ldc = N + 8
+    C = torch.full((M, ldc), 7.0, dtype=dtype, device=dev())
+    gemm(dtype, _lib.A_PLAIN, _lib.EPI_BIAS_ACT, A.to(dev(), dtype), W.to(dev(), dtype), C, M, N, K, lda=K, ldc=ldc,
+         bias=bias.to(dev()), act=act)
+    want = act_ref(A @ W.t() + bias, act)
+    assert_close(C[:, :N], want, tol(dtype, 2.0), "gemm")
+    assert torch.all(C[:, N:].float() == 7.0), "padding columns were overwritten"
+
+
+@pytest.mark.parametrize("dt", ALL)
+@pytest.mark.parametrize("M,N,K", [(300, 96, 384), (150, 256, 64), (129, 768, 3072)])
+def test_gemm_layerscale_residual(dt, M, N, K):
+    dtype = DTYPES[dt]
+    A, W = q(rnd((M, K), 1), dtype), q(rnd((N, K), 2, 1 / math.sqrt(K)), dtype)
+    bias, gamma = rnd((N,), 3, 0.1), rnd((N,), 4, 0.5)
+    X = q(rnd((M, N), 5), dtype)
+    Xd = X.to(dev(), dtype)
+    gemm(dtype, _lib.A_PLAIN, _lib.EPI_RESID, A.to(dev(), dtype), W.to(dev(), dtype), Xd, M, N, K, lda=K, ldc=N,
+         bias=bias.to(dev()), gamma=gamma.to(dev()), resid=Xd)          # in place, like the forward does
+    want = X + gamma * (A @ W.t() + bias)
+    assert_close(Xd, want, tol(dtype, 2.0), "gemm resid")
+
+
+@pytest.mark.parametrize("dt", ALL)
+@pytest.mark.parametrize("M,N,K,splitk,kps", [(8, 256, 512, 4, 128), (40, 384, 1024, 2, 512), (130, 128, 640, 3, 256)])
+def test_gemm_splitk(dt, M, N, K, splitk, kps):
+    dtype = DTYPES[dt]
+    A, W = q(rnd((M, K), 1), dtype), q(rnd((N, K), 2, 1 / math.sqrt(K)), dtype)
+    part = torch.zeros((splitk, M, N), dtype=torch.float32, device=dev())
+    gemm(dtype, _lib.A_PLAIN, _lib.EPI_SPLITK, A.to(dev(), dtype), W.to(dev(), dtype), None, M, N, K, lda=K,
+         partial=part, splitk=splitk, k_per_split=kps)
+    assert_close(part.sum(0), A @ W.t(), 2e-5 if dt == "f32" else 1e-4, "splitk")
+
+
+# ----------------------------------------------------------------------------- conv as GEMM
+@pytest.mark.parametrize("dt", ALL)
+@pytest.mark.parametrize("n,H,cin,cout", [(2, 16, 16, 32), (3, 8, 32, 64), (2, 14, 128, 256), (1, 28, 64, 128)])
+def test_conv3x3_relu_maxpool(dt, n, H, cin, cout):
+    """ED encoder layers 2-5 (model/genconvit_ed.py:18-32): conv3x3 s1 p1 -> ReLU -> maxpool2."""
+    dtype = DTYPES[dt]
+    x = q(rnd((n, cin, H, H), 1), dtype)
+    w = q(rnd((cout, cin, 3, 3), 2, 1 / math.sqrt(9 * cin)), dtype)
+    b = rnd((cout,), 3, 0.1)
+    want = F.max_pool2d(F.relu(F.conv2d(x, w, b, padding=1)), 2).permute(0, 2, 3, 1)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dev(), dtype)
+    wt = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().to(dev(), dtype)
+    out = torch.zeros((n, H // 2, H // 2, cout), dtype=dtype, device=dev())
+    gemm(dtype, _lib.A_IM2COL3_POOL, _lib.EPI_POOL4, x_nhwc, wt, out, n * H * H, cout, 9 * cin, ldc=cout,
+         bias=b.to(dev()), act=1, H=H, W=H, cin_log2=int(math.log2(cin)))
+    assert_close(out, want, tol(dtype, 2.0), "conv3 pool")
+
+
+@pytest.mark.parametrize("dt", ALL)
+@pytest.mark.parametrize("n,H,cin,cout", [(2, 16, 16, 32), (3, 8, 32, 64), (2, 28, 64, 128)])
+def test_conv3x3_stride2_leaky(dt, n, H, cin, cout):
+    """VAE encoder layers 2-4 (model/genconvit_vae.py:19-30), BatchNorm folded by the caller."""
+    dtype = DTYPES[dt]
+    x = q(rnd((n, cin, H, H), 1), dtype)
+    w = q(rnd((cout, cin, 3, 3), 2, 1 / math.sqrt(9 * cin)), dtype)
+    b = rnd((cout,), 3, 0.1)
+    want = F.leaky_relu(F.conv2d(x, w, b, stride=2, padding=1), 0.01).permute(0, 2, 3, 1)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dev(), dtype)
+    wt = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous().to(dev(), dtype)
+    out = torch.zeros((n, H // 2, H // 2, cout), dtype=dtype, device=dev())
+    gemm(dtype, _lib.A_IM2COL3_S2, _lib.EPI_BIAS_ACT, x_nhwc, wt, out, n * (H // 2) ** 2, cout, 9 * cin, ldc=cout,
+         bias=b.to(dev()), act=3, H=H, W=H, cin_log2=int(math.log2(cin)))
+    assert_close(out, want, tol(dtype, 2.0), "conv3 s2")
+
+
+@pytest.mark.parametrize("dt", ALL)
+@pytest.mark.parametrize("n,H,cin,cout,act", [(2, 7, 256, 128, 1), (3, 14, 64, 32, 3), (2, 28, 32, 16, 1)])
+def test_conv_transpose_2x2(dt, n, H, cin, cout, act):
+    """ED / VAE decoder ConvTranspose2d(k=2,s=2) layers (genconvit_ed.py:44-55, genconvit_vae.py:68-76)."""
+    dtype = DTYPES[dt]
+    x = q(rnd((n, cin, H, H), 1), dtype)
+    w = q(rnd((cin, cout, 2, 2), 2, 1 / math.sqrt(cin)), dtype)
+    b = rnd((cout,), 3, 0.1)
+    want = act_ref(F.conv_transpose2d(x, w, b, stride=2), act).permute(0, 2, 3, 1)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dev(), dtype)
+    wt = w.permute(2, 3, 1, 0).reshape(4 * cout, cin).contiguous().to(dev(), dtype)    # ((dy,dx,co), ci)
+    out = torch.zeros((n, 2 * H, 2 * H, cout), dtype=dtype, device=dev())
+    gemm(dtype, _lib.A_PLAIN, _lib.EPI_CONVT, x_nhwc, wt, out, n * H * H, 4 * cout, cin, lda=cin, bias=b.to(dev()),
+         act=act, H=H, W=H, cout_log2=int(math.log2(cout)))
+    assert_close(out, want, tol(dtype, 2.0), "convT")
+
+
+# ----------------------------------------------------------------------------- ConvNeXt pieces
+@pytest.mark.parametrize("dt", ALL)
+@pytest.mark.parametrize("layout,res", [("nchw", 224), ("nhwc", 112), ("nchw", 32)])
+def test_stem_conv4x4_layernorm(dt, layout, res):
+    dtype = DTYPES[dt]
+    n = 2
+    x = q(rnd((n, 3, res, res), 1, 2.0), dtype)
+    w = rnd((96, 3, 4, 4), 2, 0.2)
+    b, lw, lb = rnd((96,), 3, 0.1), rnd((96,), 4, 0.5) + 1.0, rnd((96,), 5, 0.1)
+    y = F.conv2d(x, w, b, stride=4).permute(0, 2, 3, 1)
+    want = F.layer_norm(y, (96,), lw, lb, 1e-6)
+    wp = w.reshape(96, 48).t().contiguous().to(dev())
+    if layout == "nchw":
+        xd = x.to(dev(), dtype)
+        st = (3 * res * res, res * res, res, 1)
+    else:
+        xd = x.permute(0, 2, 3, 1).contiguous().to(dev(), dtype)
+        st = (res * res * 3, 1, res * 3, 3)
+    out = torch.zeros((n, res // 4, res // 4, 96), dtype=dtype, device=dev())
+    kutil.call("gcv_k_stem_ln", _lib.dtype_code(dtype), ptr(xd), *st, ptr(wp), ptr(b.to(dev())), ptr(lw.to(dev())),
+               ptr(lb.to(dev())), ptr(out), n, res // 4, res // 4, 1e-6)
+    assert_close(out, want, tol(dtype, 3.0), "stem")
+
+
+@pytest.mark.parametrize("dt", ALL)
+@pytest.mark.parametrize("C,H,n", [(96, 56, 2), (96, 28, 3), (192, 28, 2), (192, 14, 1), (384, 14, 2), (384, 7, 3),
+                                   (768, 7, 2), (768, 3, 3)])
+def test_dwconv7x7_layernorm(dt, C, H, n):
+    """ConvNeXt block front half: depthwise 7x7 p3 + LayerNorm(C, eps 1e-6), NHWC."""
+    dtype = DTYPES[dt]
+    x = q(rnd((n, C, H, H), 1, 2.0), dtype)
+    w = rnd((C, 1, 7, 7), 2, 0.25)
+    b, lw, lb = rnd((C,), 3, 0.1), rnd((C,), 4, 0.5) + 1.0, rnd((C,), 5, 0.1)
+    y = F.conv2d(x, w, b, padding=3, groups=C).permute(0, 2, 3, 1)
+    want = F.layer_norm(y, (C,), lw, lb, 1e-6)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev(), dtype)
+    wdw = w.reshape(C, 49).t().contiguous().to(dev())
+    out = torch.zeros((n, H, H, C), dtype=dtype, device=dev())
+    kutil.call("gcv_k_dwconv7_ln", _lib.dtype_code(dtype), ptr(xd), ptr(wdw), ptr(b.to(dev())), ptr(lw.to(dev())),
+               ptr(lb.to(dev())), ptr(out), n, H, H, C, 1e-6)
+    assert_close(out, want, tol(dtype, 3.0), "dwconv_ln")
+
+
+@pytest.mark.parametrize("dt", ALL)
+@pytest.mark.parametrize("C,H", [(96, 56), (192, 28), (384, 14), (384, 7), (192, 14)])
+def test_layernorm2d_space_to_depth(dt, C, H):
+    """Downsample front half: LayerNorm2d + 2x2 patch gather; odd sizes drop the last row/col (7 -> 3)."""
+    dtype = DTYPES[dt]
+    n = 2
+    x = q(rnd((n, H, H, C), 1, 2.0), dtype)
+    lw, lb = rnd((C,), 4, 0.5) + 1.0, rnd((C,), 5, 0.1)
+    y = F.layer_norm(x, (C,), lw, lb, 1e-6)
+    Ho = H // 2
+    y = y[:, :2 * Ho, :2 * Ho]
+    want = y.reshape(n, Ho, 2, Ho, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(n, Ho, Ho, 4 * C)
+    out = torch.zeros((n, Ho, Ho, 4 * C), dtype=dtype, device=dev())
+    kutil.call("gcv_k_ln_patchify", _lib.dtype_code(dtype), ptr(x.to(dev(), dtype)), ptr(lw.to(dev())),
+               ptr(lb.to(dev())), ptr(out), n, H, H, C, 1e-6)
+    assert_close(out, want, tol(dtype, 3.0), "ln_patchify")
+
+
+@pytest.mark.parametrize("dt", ALL)
+@pytest.mark.parametrize("HW", [49, 9])
+def test_avgpool_layernorm(dt, HW):
+    dtype = DTYPES[dt]
+    n, C = 5, 768
+    x = q(rnd((n, HW, C), 1, 2.0), dtype)
+    lw, lb = rnd((C,), 4, 0.5) + 1.0, rnd((C,), 5, 0.1)
+    want = F.layer_norm(x.mean(1), (C,), lw, lb, 1e-6)
+    out = torch.zeros((n, C), dtype=dtype, device=dev())
+    kutil.call("gcv_k_pool_ln", _lib.dtype_code(dtype), ptr(x.to(dev(), dtype)), ptr(lw.to(dev())), ptr(lb.to(dev())),
+               ptr(out), n, HW, C, 1e-6)
+    assert_close(out, want, tol(dtype, 3.0), "pool_ln")
+
+
+@pytest.mark.parametrize("dt", ALL)
+@pytest.mark.parametrize("C", [96, 384, 1536])
+def test_layernorm_rows(dt, C):
+    dtype = DTYPES[dt]
+    rows = 37
+    x = q(rnd((rows, C), 1, 2.0), dtype)
+    lw, lb = rnd((C,), 4, 0.5) + 1.0, rnd((C,), 5, 0.1)
+    want = F.layer_norm(x, (C,), lw, lb, 1e-5)
+    out = torch.zeros((rows, C), dtype=dtype, device=dev())
+    kutil.call("gcv_k_layernorm_rows", _lib.dtype_code(dtype), ptr(x.to(dev(), dtype)), ptr(lw.to(dev())),
+               ptr(lb.to(dev())), ptr(out), rows, C, 1e-5)
+    assert_close(out, want, tol(dtype, 3.0), "layernorm_rows")
+
+
+# ----------------------------------------------------------------------------- AE / VAE small kernels
+@pytest.mark.parametrize("dt", ALL)
+@pytest.mark.parametrize("pool", [True, False])
+def test_first_conv_3_to_16(dt, pool):
+    dtype = DTYPES[dt]
+    n, H = 2, 32
+    x = q(rnd((n, 3, H, H), 1, 2.0), dtype)
+    w = rnd((16, 3, 3, 3), 2, 0.3)
+    b = rnd((16,), 3, 0.1)
+    if pool:
+        want = F.max_pool2d(F.relu(F.conv2d(x, w, b, padding=1)), 2)
+        act = 1
+    else:
+        want = F.leaky_relu(F.conv2d(x, w, b, stride=2, padding=1), 0.01)
+        act = 3
+    want = want.permute(0, 2, 3, 1)
+    wp = w.permute(2, 3, 1, 0).reshape(27, 16).contiguous().to(dev())
+    out = torch.zeros((n, H // 2, H // 2, 16), dtype=dtype, device=dev())
+    kutil.call("gcv_k_conv3_first", _lib.dtype_code(dtype), ptr(x.to(dev(), dtype)), 3 * H * H, H * H, H, 1, ptr(wp),
+               ptr(b.to(dev())), ptr(out), n, H, H, int(pool), act)
+    assert_close(out, want, tol(dtype, 3.0), "conv3_first")
+
+
+@pytest.mark.parametrize("dt", ALL)
+@pytest.mark.parametrize("act", [1, 3])
+def test_last_conv_transpose_16_to_3(dt, act):
+    dtype = DTYPES[dt]
+    n, H = 2, 12
+    x = q(rnd((n, 16, H, H), 1, 2.0), dtype)
+    w = rnd((16, 3, 2, 2), 2, 0.3)
+    b = rnd((3,), 3, 0.1)
+    want = act_ref(F.conv_transpose2d(x, w, b, stride=2), act).permute(0, 2, 3, 1)
+    wp = w.permute(0, 2, 3, 1).reshape(16, 12).contiguous().to(dev())
+    out = torch.zeros((n, 2 * H, 2 * H, 3), dtype=dtype, device=dev())
+    kutil.call("gcv_k_convt2_small", _lib.dtype_code(dtype), ptr(x.permute(0, 2, 3, 1).contiguous().to(dev(), dtype)),
+               ptr(wp), ptr(b.to(dev())), ptr(out), n, H, H, act)
+    assert_close(out, want, tol(dtype, 3.0), "convt2_small")
+
+
+@pytest.mark.parametrize("dt", ALL)
+def test_reparameterise_from_splitk(dt):
+    """z = eps*exp(0.5*mu) + mu with std taken from mu (model/genconvit_vae.py:45-47), written NHWC."""
+    dtype = DTYPES[dt]
+    B, N, S = 3, 12544, 4
+    part = rnd((S, B, N), 1, 0.4)
+    bias, eps = rnd((N,), 2, 0.1), torch.randn((B, N), generator=torch.Generator().manual_seed(3))
+    mu = part.sum(0) + bias
+    z = eps * torch.exp(0.5 * mu) + mu
+    want = z.reshape(B, 256, 49).permute(0, 2, 1).reshape(B, N)
+    mu_out = torch.zeros((B, N), dtype=torch.float32, device=dev())
+    zout = torch.zeros((B, N), dtype=dtype, device=dev())
+    kutil.call("gcv_k_reparam", _lib.dtype_code(dtype), ptr(part.to(dev())), S, ptr(bias.to(dev())), ptr(eps.to(dev())),
+               ptr(mu_out), ptr(zout), B, N)
+    assert_close(mu_out, mu, 1e-5, "mu")
+    assert_close(zout, want, tol(dtype, 8.0), "z")
+
+
+@pytest.mark.parametrize("dt", ALL)
+def test_head_tail(dt):
+    dtype = DTYPES[dt]
+    B, K = 9, 500
+    h = q(rnd((B, K), 1), dtype)
+    w, b = rnd((2, K), 2, 0.05), rnd((2,), 3, 0.1)
+    out = torch.zeros((B, 2), dtype=torch.float32, device=dev())
+    kutil.call("gcv_k_head_tail", _lib.dtype_code(dtype), ptr(h.to(dev(), dtype)), ptr(w.to(dev())), ptr(b.to(dev())),
+               ptr(out), B, K)
+    assert_close(out, h @ w.t() + b, 1e-5, "head tail")
+
+
+@pytest.mark.parametrize("dt", ALL)
+def test_bilinear_resize_and_mse(dt):
+    """transforms.Resize((224,224)) of x_hat (genconvit_vae.py:116) + per-frame MSE (train/train_vae.py:24)."""
+    dtype = DTYPES[dt]
+    B = 2
+    xhat = q(rnd((B, 3, 112, 112), 1, 2.0), dtype)
+    img = q(rnd((B, 3, 224, 224), 2, 2.0), dtype)
+    want = F.interpolate(xhat, size=(224, 224), mode="bilinear", align_corners=False, antialias=True)
+    recon = torch.zeros((B, 3, 224, 224), dtype=dtype, device=dev())
+    msepart = torch.zeros((B, 196), dtype=torch.float32, device=dev())
+    mse = torch.zeros((B,), dtype=torch.float32, device=dev())
+    kutil.call("gcv_k_resize_mse", _lib.dtype_code(dtype), ptr(xhat.permute(0, 2, 3, 1).contiguous().to(dev(), dtype)),
+               ptr(img.to(dev(), dtype)), ptr(recon), ptr(msepart), ptr(mse), B)
+    assert_close(recon, want, tol(dtype, 3.0), "resize")
+    want_mse = ((want - img) ** 2).flatten(1).mean(1)
+    assert_close(mse, want_mse, 1e-4 * float(want_mse.max()), "mse")
+
+
+def test_vote_sigmoid_mean():
+    logits = rnd((37, 2), 1, 3.0)
+    got = _lib.vote(logits.to(dev()))
+    torch.cuda.synchronize()
+    assert_close(got, torch.sigmoid(logits).mean(0), 1e-6, "vote")
+
+
+# ----------------------------------------------------------------------------- error behaviour
+def test_errors_are_raised_not_swallowed():
+    with pytest.raises(_lib.GenConViTHipError, match="multiple of the 16-byte chunk"):
+        A = torch.zeros((4, 6), device=dev())
+        gemm(torch.float32, _lib.A_PLAIN, _lib.EPI_BIAS_ACT, A, A, A, 4, 4, 6, lda=6, ldc=4)
+    with pytest.raises(_lib.GenConViTHipError, match="C must be one of"):
+        x = torch.zeros((1, 7, 7, 100), device=dev())
+        kutil.call("gcv_k_dwconv7_ln", 0, ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), 1, 7, 7, 100, 1e-6)

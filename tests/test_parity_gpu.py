@@ -1,0 +1,200 @@
+"""End-to-end parity on the MI355X: the HIP path (through the host mirror classes -> ctypes -> C ABI)
+against (a) the committed golden vectors produced by the reference's own classes
+(tests/golden/make_golden.py) and (b) the CPU oracle on the same seeded inputs.
+
+Tolerance: north_star's "logits within 1e-3 of the reference PyTorch CPU path" for fp32 storage.
+16-bit storage (bf16 / fp16, "--fp16" of the reference) is reported against the fp32 oracle with the
+looser bound written in each test.
+"""
+import numpy as np
+import pytest
+import torch
+
+from genconvit_amd import _lib, synth
+from genconvit_amd.model.config import load_config
+from genconvit_amd.model.genconvit import GenConViT
+from genconvit_amd.model.genconvit_ed import GenConViTED
+from genconvit_amd.model.genconvit_vae import GenConViTVAE
+from genconvit_amd.model import pred_func
+from oracle import cpu_ref
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+FP32_TOL = 1e-3          # north_star
+_CACHE = {}
+
+
+def slice64(t):
+    f = t.detach().float().cpu().flatten()
+    idx = torch.linspace(0, f.numel() - 1, 64).long()
+    return f[idx].numpy()
+
+
+def ed_model(dtype=torch.float32):
+    key = ("ed", dtype)
+    if key not in _CACHE:
+        m = GenConViTED(load_config(), init="empty")
+        from tests.conftest import synthetic_sd
+        m.load_state_dict(synthetic_sd("ed"))
+        _CACHE[key] = m.to("cuda").to(dtype).eval()
+    return _CACHE[key]
+
+
+def vae_model(dtype=torch.float32):
+    key = ("vae", dtype)
+    if key not in _CACHE:
+        m = GenConViTVAE(load_config(), init="empty")
+        from tests.conftest import synthetic_sd
+        m.load_state_dict(synthetic_sd("vae"))
+        _CACHE[key] = m.to("cuda").to(dtype).eval()
+    return _CACHE[key]
+
+
+# ----------------------------------------------------------------------------- fp32: the parity gate
+def test_ed_fp32_matches_reference_golden(golden, sd_ed):
+    x = synth.make_frames(4)
+    got = ed_model()(x.cuda()).cpu()
+    err_gold = np.abs(got.numpy() - golden["ed_logits"]).max()
+    err_orc = (got - cpu_ref.ed_forward(sd_ed, x)).abs().max().item()
+    print(f"\nED fp32 B=4: |logits - reference golden| = {err_gold:.3e}, vs oracle = {err_orc:.3e}")
+    assert err_gold <= FP32_TOL and err_orc <= FP32_TOL
+
+
+@pytest.mark.parametrize("res", [224, 112])
+def test_convnext_fp32_matches_oracle(res, sd_ed):
+    x = synth.make_frames(3, name=f"cnx{res}")
+    if res != 224:
+        x = torch.nn.functional.avg_pool2d(x, 224 // res)
+    got = ed_model().backbone_forward(x.cuda()).cpu()
+    want = cpu_ref.convnext_tiny(sd_ed, "backbone.", x)
+    err = (got - want).abs().max().item()
+    print(f"\nConvNeXt-T fp32 @{res}: max |logits1000 diff| = {err:.3e} (|want| max {want.abs().max():.2f})")
+    assert err <= FP32_TOL
+
+
+def test_vae_fp32_matches_reference_golden(golden, sd_vae):
+    x = synth.make_frames(4)
+    eps = torch.from_numpy(golden["vae_eps"])
+    m = vae_model()
+    logits, recon = m(x.cuda(), eps=eps.cuda(), want_recon=True, want_mse=True, want_kl=True)
+    err_gold = np.abs(logits.cpu().numpy() - golden["vae_logits"]).max()
+    print(f"\nVAE fp32 B=4: |logits - reference golden| = {err_gold:.3e}")
+    assert err_gold <= FP32_TOL
+    assert np.abs(slice64(recon) - golden["vae_recon_slice"]).max() <= 1e-3
+    assert np.abs(m.mse.cpu().numpy() - golden["vae_mse"]).max() <= 1e-3 * golden["vae_mse"].max()
+    assert abs(float(m.kl) - float(golden["vae_kl"])) <= 1e-4 * abs(float(golden["vae_kl"]))
+    assert recon.shape == (4, 3, 224, 224)
+
+
+def test_genconvit_concat_and_vote_match_reference_golden(golden):
+    x = synth.make_frames(4)
+    eps = torch.from_numpy(golden["vae_eps"])
+    g = GenConViT.from_modules(ed_model(), vae_model(), net="genconvit")
+    out = g(x.cuda(), eps=eps.cuda())
+    assert out.shape == (8, 2)                                  # cat((ed, vae), dim=0), model/genconvit.py:74
+    assert np.abs(out.cpu().numpy() - golden["genconvit_logits"]).max() <= FP32_TOL
+    y, val = pred_func.max_prediction_value(torch.sigmoid(out.squeeze()))
+    assert y == int(golden["vote_idx"]) and abs(val - float(golden["vote_val"])) <= 1e-3
+    assert pred_func.real_or_fake(y) == str(golden["vote_label"])
+    dv = _lib.vote(out).cpu()                                   # device-side K15
+    assert abs(float(dv[y]) - torch.sigmoid(out).mean(0)[y].item()) <= 1e-6
+    for net, rows in (("ed", 4), ("vae", 4)):
+        o = GenConViT.from_modules(ed_model(), vae_model(), net=net)(x.cuda(), eps=eps.cuda())
+        assert o.shape == (rows, 2)
+        ref = golden["ed_logits"] if net == "ed" else golden["vae_logits"]
+        assert np.abs(o.cpu().numpy() - ref).max() <= FP32_TOL
+
+
+def test_pred_vid_drop_in(golden):
+    """pred_vid(df, model) of model/pred_func.py:111-120 on CPU frames with the VAE eps pinned."""
+    x = synth.make_frames(4)
+    eps = torch.from_numpy(golden["vae_eps"]).cuda()
+    g = GenConViT.from_modules(ed_model(), vae_model(), net="genconvit")
+    fwd = g.forward
+    g.forward = lambda df: fwd(df, eps=eps)          # pin the RNG draw for the check
+    y, val = pred_func.pred_vid(x, g)                # x on CPU: moved to the model device like the reference
+    assert y == int(golden["vote_idx"]) and abs(val - float(golden["vote_val"])) <= 1e-3
+
+
+# ----------------------------------------------------------------------------- edge cases / properties
+def test_batch_of_one_and_ragged_batches(sd_ed):
+    x = synth.make_frames(7, name="ragged")
+    m = ed_model()
+    full = m(x.cuda()).cpu()
+    one = m(x[:1].cuda()).cpu()
+    assert one.shape == (1, 2)
+    assert (one - full[:1]).abs().max().item() <= 1e-5
+    parts = torch.cat([m(x[0:3].cuda()).cpu(), m(x[3:7].cuda()).cpu()])
+    assert (parts - full).abs().max().item() <= 1e-5           # frames are independent (shardable)
+    assert (full - cpu_ref.ed_forward(sd_ed, x)).abs().max().item() <= FP32_TOL
+
+
+def test_shards_reassemble_to_unsharded_result(golden):
+    """§8e: 8 shards run one after the other on one GPU == the unsharded (2B,2) tensor."""
+    from genconvit_amd import dist as gdist
+    B, world = 11, 8
+    x = synth.make_frames(B, name="shard").cuda()
+    eps = synth.make_eps(B).cuda()
+    g = GenConViT.from_modules(ed_model(), vae_model(), net="genconvit")
+    full = g(x, eps=eps).cpu()
+    ed_rows, vae_rows = [], []
+    for r in range(world):
+        lo, hi = gdist.shard_bounds(B, world, r)
+        if hi == lo:
+            continue
+        o = g(x[lo:hi], eps=eps[lo:hi]).cpu()
+        ed_rows.append(o[:hi - lo])
+        vae_rows.append(o[hi - lo:])
+    re = torch.cat(ed_rows + vae_rows)
+    assert re.shape == full.shape and (re - full).abs().max().item() <= 1e-5
+
+
+def test_full_size_config2_ed_batch32_fp32(sd_ed):
+    """BASELINE.json configs[1]: ed, batch 32, fp32 — every frame against the oracle."""
+    x = synth.make_frames(32, name="cfg2")
+    got = ed_model()(x.cuda()).cpu()
+    want = cpu_ref.ed_forward(sd_ed, x)
+    err = (got - want).abs().max().item()
+    print(f"\nED fp32 B=32: max |logits diff| = {err:.3e}")
+    assert err <= FP32_TOL and torch.isfinite(got).all()
+
+
+def test_input_dtype_and_device_are_normalised():
+    x = synth.make_frames(2)
+    m = ed_model()
+    a = m(x.cuda())
+    b = m(x.double())            # CPU + wrong dtype: moved / cast at the boundary
+    assert (a - b).abs().max().item() <= 1e-6
+
+
+def test_missing_weight_key_is_an_error():
+    from tests.conftest import synthetic_sd
+    sd = dict(synthetic_sd("ed"))
+    sd.pop("backbone.stages.2.blocks.4.gamma")
+    h = _lib.Handle(0, torch.float32, 2)
+    with pytest.raises(_lib.GenConViTHipError, match="missing weight tensor 'backbone.stages.2.blocks.4.gamma'"):
+        h.load_ed(sd)
+    with pytest.raises(_lib.GenConViTHipError, match="not loaded"):
+        h.ed_forward(torch.zeros(1, 3, 224, 224, device="cuda"))
+    h.close()
+
+
+# ----------------------------------------------------------------------------- 16-bit storage
+@pytest.mark.parametrize("dtype,bound", [(torch.bfloat16, 8e-2), (torch.float16, 2e-2)])
+def test_ed_16bit_delta_vs_fp32_oracle(dtype, bound, golden):
+    x = synth.make_frames(4)
+    got = ed_model(dtype)(x.cuda()).cpu()
+    err = np.abs(got.numpy() - golden["ed_logits"]).max()
+    print(f"\nED {dtype} B=4: |logits - fp32 reference golden| = {err:.3e}")
+    assert err <= bound
+
+
+@pytest.mark.parametrize("dtype,bound", [(torch.bfloat16, 1.5e-1), (torch.float16, 3e-2)])
+def test_vae_16bit_delta_vs_fp32_oracle(dtype, bound, golden):
+    x = synth.make_frames(4)
+    eps = torch.from_numpy(golden["vae_eps"])
+    logits, _ = vae_model(dtype)(x.cuda(), eps=eps.cuda(), want_recon=False)
+    err = np.abs(logits.cpu().numpy() - golden["vae_logits"]).max()
+    print(f"\nVAE {dtype} B=4: |logits - fp32 reference golden| = {err:.3e}")
+    assert err <= bound
