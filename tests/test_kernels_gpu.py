@@ -17,6 +17,20 @@ torch.set_grad_enabled(False)
 ALL = ["f32", "bf16", "f16"]
 
 
+_KEEP = []
+
+
+def D(t, dtype=None):
+    """device copy that stays alive for the duration of the test (the caching allocator would
+    otherwise hand a freed temporary's block to the next one before the kernel has run)"""
+    d = t.to(dev()) if dtype is None else t.to(dev(), dtype)
+    _KEEP.append(d)
+    if len(_KEEP) > 64:
+        torch.cuda.synchronize()
+        del _KEEP[:32]
+    return d
+
+
 def q(t, dtype):
     """round a fp32 CPU tensor through the storage dtype"""
     return t.to(dtype).float()
@@ -150,8 +164,8 @@ def test_stem_conv4x4_layernorm(dt, layout, res):
         xd = x.permute(0, 2, 3, 1).contiguous().to(dev(), dtype)
         st = (res * res * 3, 1, res * 3, 3)
     out = torch.zeros((n, res // 4, res // 4, 96), dtype=dtype, device=dev())
-    kutil.call("gcv_k_stem_ln", _lib.dtype_code(dtype), ptr(xd), *st, ptr(wp), ptr(b.to(dev())), ptr(lw.to(dev())),
-               ptr(lb.to(dev())), ptr(out), n, res // 4, res // 4, 1e-6)
+    kutil.call("gcv_k_stem_ln", _lib.dtype_code(dtype), ptr(xd), *st, ptr(wp), ptr(D(b)), ptr(D(lw)),
+               ptr(D(lb)), ptr(out), n, res // 4, res // 4, 1e-6)
     assert_close(out, want, tol(dtype, 3.0), "stem")
 
 
@@ -169,8 +183,8 @@ def test_dwconv7x7_layernorm(dt, C, H, n):
     xd = x.permute(0, 2, 3, 1).contiguous().to(dev(), dtype)
     wdw = w.reshape(C, 49).t().contiguous().to(dev())
     out = torch.zeros((n, H, H, C), dtype=dtype, device=dev())
-    kutil.call("gcv_k_dwconv7_ln", _lib.dtype_code(dtype), ptr(xd), ptr(wdw), ptr(b.to(dev())), ptr(lw.to(dev())),
-               ptr(lb.to(dev())), ptr(out), n, H, H, C, 1e-6)
+    kutil.call("gcv_k_dwconv7_ln", _lib.dtype_code(dtype), ptr(xd), ptr(wdw), ptr(D(b)), ptr(D(lw)),
+               ptr(D(lb)), ptr(out), n, H, H, C, 1e-6)
     assert_close(out, want, tol(dtype, 3.0), "dwconv_ln")
 
 
@@ -187,8 +201,8 @@ def test_layernorm2d_space_to_depth(dt, C, H):
     y = y[:, :2 * Ho, :2 * Ho]
     want = y.reshape(n, Ho, 2, Ho, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(n, Ho, Ho, 4 * C)
     out = torch.zeros((n, Ho, Ho, 4 * C), dtype=dtype, device=dev())
-    kutil.call("gcv_k_ln_patchify", _lib.dtype_code(dtype), ptr(x.to(dev(), dtype)), ptr(lw.to(dev())),
-               ptr(lb.to(dev())), ptr(out), n, H, H, C, 1e-6)
+    kutil.call("gcv_k_ln_patchify", _lib.dtype_code(dtype), ptr(D(x, dtype)), ptr(D(lw)),
+               ptr(D(lb)), ptr(out), n, H, H, C, 1e-6)
     assert_close(out, want, tol(dtype, 3.0), "ln_patchify")
 
 
@@ -201,7 +215,7 @@ def test_avgpool_layernorm(dt, HW):
     lw, lb = rnd((C,), 4, 0.5) + 1.0, rnd((C,), 5, 0.1)
     want = F.layer_norm(x.mean(1), (C,), lw, lb, 1e-6)
     out = torch.zeros((n, C), dtype=dtype, device=dev())
-    kutil.call("gcv_k_pool_ln", _lib.dtype_code(dtype), ptr(x.to(dev(), dtype)), ptr(lw.to(dev())), ptr(lb.to(dev())),
+    kutil.call("gcv_k_pool_ln", _lib.dtype_code(dtype), ptr(D(x, dtype)), ptr(D(lw)), ptr(D(lb)),
                ptr(out), n, HW, C, 1e-6)
     assert_close(out, want, tol(dtype, 3.0), "pool_ln")
 
@@ -215,8 +229,8 @@ def test_layernorm_rows(dt, C):
     lw, lb = rnd((C,), 4, 0.5) + 1.0, rnd((C,), 5, 0.1)
     want = F.layer_norm(x, (C,), lw, lb, 1e-5)
     out = torch.zeros((rows, C), dtype=dtype, device=dev())
-    kutil.call("gcv_k_layernorm_rows", _lib.dtype_code(dtype), ptr(x.to(dev(), dtype)), ptr(lw.to(dev())),
-               ptr(lb.to(dev())), ptr(out), rows, C, 1e-5)
+    kutil.call("gcv_k_layernorm_rows", _lib.dtype_code(dtype), ptr(D(x, dtype)), ptr(D(lw)),
+               ptr(D(lb)), ptr(out), rows, C, 1e-5)
     assert_close(out, want, tol(dtype, 3.0), "layernorm_rows")
 
 
@@ -238,8 +252,8 @@ def test_first_conv_3_to_16(dt, pool):
     want = want.permute(0, 2, 3, 1)
     wp = w.permute(2, 3, 1, 0).reshape(27, 16).contiguous().to(dev())
     out = torch.zeros((n, H // 2, H // 2, 16), dtype=dtype, device=dev())
-    kutil.call("gcv_k_conv3_first", _lib.dtype_code(dtype), ptr(x.to(dev(), dtype)), 3 * H * H, H * H, H, 1, ptr(wp),
-               ptr(b.to(dev())), ptr(out), n, H, H, int(pool), act)
+    kutil.call("gcv_k_conv3_first", _lib.dtype_code(dtype), ptr(D(x, dtype)), 3 * H * H, H * H, H, 1, ptr(wp),
+               ptr(D(b)), ptr(out), n, H, H, int(pool), act)
     assert_close(out, want, tol(dtype, 3.0), "conv3_first")
 
 
@@ -254,8 +268,8 @@ def test_last_conv_transpose_16_to_3(dt, act):
     want = act_ref(F.conv_transpose2d(x, w, b, stride=2), act).permute(0, 2, 3, 1)
     wp = w.permute(0, 2, 3, 1).reshape(16, 12).contiguous().to(dev())
     out = torch.zeros((n, 2 * H, 2 * H, 3), dtype=dtype, device=dev())
-    kutil.call("gcv_k_convt2_small", _lib.dtype_code(dtype), ptr(x.permute(0, 2, 3, 1).contiguous().to(dev(), dtype)),
-               ptr(wp), ptr(b.to(dev())), ptr(out), n, H, H, act)
+    kutil.call("gcv_k_convt2_small", _lib.dtype_code(dtype), ptr(D(x.permute(0, 2, 3, 1).contiguous(), dtype)),
+               ptr(wp), ptr(D(b)), ptr(out), n, H, H, act)
     assert_close(out, want, tol(dtype, 3.0), "convt2_small")
 
 
@@ -271,7 +285,7 @@ def test_reparameterise_from_splitk(dt):
     want = z.reshape(B, 256, 49).permute(0, 2, 1).reshape(B, N)
     mu_out = torch.zeros((B, N), dtype=torch.float32, device=dev())
     zout = torch.zeros((B, N), dtype=dtype, device=dev())
-    kutil.call("gcv_k_reparam", _lib.dtype_code(dtype), ptr(part.to(dev())), S, ptr(bias.to(dev())), ptr(eps.to(dev())),
+    kutil.call("gcv_k_reparam", _lib.dtype_code(dtype), ptr(D(part)), S, ptr(D(bias)), ptr(D(eps)),
                ptr(mu_out), ptr(zout), B, N)
     assert_close(mu_out, mu, 1e-5, "mu")
     assert_close(zout, want, tol(dtype, 8.0), "z")
@@ -284,7 +298,7 @@ def test_head_tail(dt):
     h = q(rnd((B, K), 1), dtype)
     w, b = rnd((2, K), 2, 0.05), rnd((2,), 3, 0.1)
     out = torch.zeros((B, 2), dtype=torch.float32, device=dev())
-    kutil.call("gcv_k_head_tail", _lib.dtype_code(dtype), ptr(h.to(dev(), dtype)), ptr(w.to(dev())), ptr(b.to(dev())),
+    kutil.call("gcv_k_head_tail", _lib.dtype_code(dtype), ptr(D(h, dtype)), ptr(D(w)), ptr(D(b)),
                ptr(out), B, K)
     assert_close(out, h @ w.t() + b, 1e-5, "head tail")
 
@@ -300,8 +314,8 @@ def test_bilinear_resize_and_mse(dt):
     recon = torch.zeros((B, 3, 224, 224), dtype=dtype, device=dev())
     msepart = torch.zeros((B, 196), dtype=torch.float32, device=dev())
     mse = torch.zeros((B,), dtype=torch.float32, device=dev())
-    kutil.call("gcv_k_resize_mse", _lib.dtype_code(dtype), ptr(xhat.permute(0, 2, 3, 1).contiguous().to(dev(), dtype)),
-               ptr(img.to(dev(), dtype)), ptr(recon), ptr(msepart), ptr(mse), B)
+    kutil.call("gcv_k_resize_mse", _lib.dtype_code(dtype), ptr(D(xhat.permute(0, 2, 3, 1).contiguous(), dtype)),
+               ptr(D(img, dtype)), ptr(recon), ptr(msepart), ptr(mse), B)
     assert_close(recon, want, tol(dtype, 3.0), "resize")
     want_mse = ((want - img) ** 2).flatten(1).mean(1)
     assert_close(mse, want_mse, 1e-4 * float(want_mse.max()), "mse")
