@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec of the GenConViT (ed+vae) forward on N MI355X, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic frames already resident in HBM:
+    genconvit forward (ED + VAE, model/genconvit.py:66-75) on this rank's 128-frame shard
+    -> (N>1) RCCL all-gather of the per-frame logits -> sigmoid/mean vote on device.
+Workload at N=1 = BASELINE.json configs[3] ("genconvit, batch=128, 1xMI355X, fp16"), at N>1 =
+configs[4] (128 frames per GPU, weak scaling).  Weights are random-init of the reference
+architecture from the in-repo deterministic generator; frames are synthetic (no datasets here).
+
+Rank 0 prints ONE JSON line: metric/value (whole-job frames/s), ms_per_step, plus
+  "roofline"     — the dominant kernel family of the step, timed live with HIP events on the
+                   launch stream (gcv_profile_*), algorithmic FLOPs/bytes from the launch shapes
+  "cpu_baseline" — the CPU oracle (a port of the reference's PyTorch CPU path; the reference itself
+                   cannot run without timm) timed on this host's cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from genconvit_amd import _lib, dist as gdist, spec, synth          # noqa: E402
+from genconvit_amd.model.config import load_config                  # noqa: E402
+from genconvit_amd.model.genconvit import GenConViT                 # noqa: E402
+from genconvit_amd.model.genconvit_ed import GenConViTED            # noqa: E402
+from genconvit_amd.model.genconvit_vae import GenConViTVAE          # noqa: E402
+
+PEAK = {  # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks, HBM3E spec
+    "mfma": {"f32": 157.3, "f16": 2500.0, "bf16": 2500.0},   # TFLOP/s
+    "hbm": 8000.0,                                             # GB/s
+}
+DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+GFLOP_PER_FRAME = {"ed": 18.39, "vae": 11.78, "genconvit": 30.17}   # BASELINE.md §2 (algorithmic)
+
+
+def host_cores() -> int:
+    """CPU cores this process may actually use: cgroup quota if set (the GPU box exposes 256 logical
+    CPUs but grants a 16-core share), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return min(n, int(os.environ.get("GCV_HOST_CORES", "32")))
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--net", default="genconvit", choices=["ed", "vae", "genconvit"])
+    ap.add_argument("--batch", type=int, default=128, help="frames per GPU")
+    ap.add_argument("--dtype", default="f16", choices=["f32", "f16", "bf16"])
+    ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def build_models(net, dtype, batch, device):
+    cfg = load_config()
+    ed = vae = None
+    sds = {}
+    if net != "vae":
+        sds["ed"] = synth.make_state_dict(spec.ed_spec(), synth.DEFAULT_SEED, "ed/", device=device)
+        ed = GenConViTED(cfg, init="empty")
+        ed.load_state_dict(sds["ed"])
+        ed = ed.to(device).to(dtype).eval().reserve(batch)
+    if net != "ed":
+        sds["vae"] = synth.make_state_dict(spec.vae_spec(include_unused=False), synth.DEFAULT_SEED, "vae/", device=device)
+        vae = GenConViTVAE(cfg, init="empty")
+        vae.load_state_dict(sds["vae"], strict=False)
+        vae = vae.to(device).to(dtype).eval().reserve(batch)
+    return GenConViT.from_modules(ed, vae, net=net), sds
+
+
+def cpu_baseline(net, sds, seconds):
+    """Oracle (CPU port of the reference's PyTorch path, as written: 3x mu + var GEMMs) on the host
+    cores, reference config[0] shape (batch 4).  Bounded to ~`seconds` of CPU work."""
+    from oracle import cpu_ref
+    torch.set_num_threads(host_cores())
+    cpu = {k: {n: t.float().cpu() for n, t in sd.items()} for k, sd in sds.items()}
+    if "vae" in cpu and "encoder.var.weight" not in cpu["vae"]:
+        cpu["vae"]["encoder.var.weight"] = cpu["vae"]["encoder.mu.weight"]
+        cpu["vae"]["encoder.var.bias"] = cpu["vae"]["encoder.mu.bias"]
+    B = 4
+    x = synth.make_frames(B, name="cpu_baseline")
+    eps = synth.make_eps(B)
+    fwd = lambda: cpu_ref.genconvit_forward(cpu.get("ed"), cpu.get("vae"), x, eps, net=net, as_written=True)
+    with torch.no_grad():
+        fwd()                                    # warm-up
+        times = []
+        t_end = time.perf_counter() + seconds
+        while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 50):
+            t0 = time.perf_counter()
+            fwd()
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(B / med, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{net} forward, batch {B}, fp32, oracle/cpu_ref.py as-written (3x mu + var GEMMs), "
+                      f"median of {len(times)} iterations after 1 warm-up"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("for --gpus N>1 launch with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {a.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the HIP path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=device)
+    torch.set_grad_enabled(False)
+    torch.set_num_threads(host_cores())
+    log(f"host cores usable: {host_cores()} (os.cpu_count() = {os.cpu_count()})")
+
+    dtype = DT[a.dtype]
+    nets = 2 if a.net == "genconvit" else 1
+    model, sds = build_models(a.net, dtype, a.batch, device)
+    log("models built (synthetic weights generated on device)")
+    # every rank holds its own 128-frame shard of the global batch (weak scaling)
+    n_global = a.batch * world
+    lo, hi = gdist.shard_bounds(n_global, world, rank)
+    x = synth.make_frames(hi - lo, name=f"bench_frames_r{rank}").to(device).to(dtype)
+    eps = synth.make_eps(hi - lo, name=f"bench_eps_r{rank}").to(device)
+
+    def step():
+        logits = model(x, eps=eps)
+        if world > 1:
+            logits = gdist.gather_logits(logits, n_global, nets)
+        return _lib.vote(logits)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    log("warm-up done")
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out).all()
+    log(f"timed region: {a.steps} steps in {dt:.3f} s")
+
+    # ---- roofline of the dominant kernel family: HIP events around every launch (separate steps so
+    #      the event records do not perturb the timed region) --------------------------------------
+    roof = None
+    if rank == 0:
+        handles = [m._handle for m in (getattr(model, "model_ed", None), getattr(model, "model_vae", None)) if m is not None]
+        for h in handles:
+            h.profile_enable(True)
+        agg = {}
+        for _ in range(max(a.profile_steps, 1)):
+            step()
+            torch.cuda.synchronize()
+            for h in handles:
+                for r in h.profile_report():
+                    g = agg.setdefault(r["tag"], {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+                    for k in ("launches", "ms", "flops", "bytes"):
+                        g[k] += r[k]
+        for h in handles:
+            h.profile_enable(False)
+        total_ms = sum(v["ms"] for v in agg.values())
+        # kernel families: the two pointwise GEMMs are the same kernel template (gemm_kernel, plain A)
+        fam = {}
+        for tag, v in agg.items():
+            f = "mfma_gemm(cnx.pw1_gelu+cnx.pw2_scale_res)" if tag in ("cnx.pw1_gelu", "cnx.pw2_scale_res") else tag
+            g = fam.setdefault(f, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            for k in g:
+                g[k] += v[k]
+        name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
+        bound = "mfma" if name.startswith("mfma_gemm") or "gemm" in name else "hbm"
+        avg_ms = d["ms"] / d["launches"]
+        if bound == "mfma":
+            achieved = d["flops"] / d["launches"] / (avg_ms * 1e-3) / 1e12
+            peak, unit = PEAK["mfma"][a.dtype], "TFLOP/s"
+        else:
+            achieved = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
+            peak, unit = PEAK["hbm"], "GB/s"
+        roof = {"kernel": name, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+                "frac": round(achieved / peak, 4), "traffic": None,
+                "launches_per_step": d["launches"] // max(a.profile_steps, 1), "avg_launch_ms": round(avg_ms, 4),
+                "share_of_step": round(d["ms"] / total_ms, 3),
+                "breakdown_ms_per_step": {k: round(v["ms"] / max(a.profile_steps, 1), 3)
+                                          for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}}
+
+    log("kernel profile pass done")
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.net, sds, a.cpu_seconds)
+
+    if rank == 0:
+        fps = n_global * a.steps / dt
+        line = {
+            "metric": "frames/sec (224x224, ed+vae forward)" if a.net == "genconvit" else f"frames/sec (224x224, {a.net} forward)",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"{a.net} (ed+vae) forward, {a.batch} frames/GPU x {world} GPU, 224x224x3, "
+                                   f"{a.dtype} storage / fp32 accumulate" + (", RCCL logit all-gather + vote" if world > 1 else ", vote"),
+                       "net": a.net, "frames_per_gpu": a.batch, "global_batch": n_global,
+                       "parallelism": f"frame-shard x{world}", "algorithmic_gflop_per_frame": GFLOP_PER_FRAME[a.net]},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

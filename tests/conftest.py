@@ -8,7 +8,20 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 
+def _host_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return min(n, 32)
+
+
 def pytest_configure(config):
+    import torch
+    torch.set_num_threads(_host_cores())     # the GPU box shows 256 CPUs but grants a 16-core share
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
 
