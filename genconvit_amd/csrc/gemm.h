@@ -13,8 +13,11 @@
 //   16-bit : v_mfma_f32_32x32x16_{f16,bf16}   lane (r=l&31,h=l>>5) holds k = 8h..8h+7 of row r
 //   fp32   : v_mfma_f32_32x32x2_f32 x4        lane half h supplies k = 4h+j in sub-step j
 // (the k permutation inside a chunk pair is the same for A and Wt, so the sum is unchanged).
-// LDS rows are BKB bytes (64 for fp32, 128 for 16-bit) with the chunk index XOR-swizzled by
-// the row so the 16-lane groups of ds_read_b128 touch all 64 banks exactly once.
+// LDS rows are BKB bytes (64 for fp32, 128 for 16-bit, 64 for 16-bit GEMMs whose K is 32 mod 64) with
+// the chunk index XOR-swizzled by the row so the 16-lane groups of ds_read_b128 touch all 64 banks once.
+// Epilogue: the Wt fragment is fed as the MFMA A operand, so a lane owns one TOKEN and 4 consecutive
+// registers are 4 consecutive output channels; bias/activation/layer-scale run in registers, the tile
+// is staged through LDS and written back with 8-16 B per lane over contiguous channels.
 #pragma once
 #include "common.h"
 
@@ -66,21 +69,53 @@ template <> struct Mfma<bf16_t> {
   }
 };
 
-template <typename T, int BM, int BN, int WM, int WN, int AMODE, int EPI>
+// Branch-free erf (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7 analytically, 6e-7 in fp32): the
+// libm erff is ~100 branchy instructions and made the GELU epilogue 5x the MFMA time of a K=96 GEMM.
+__device__ __forceinline__ float erf_fast(float x) {
+  const float a = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  const float e = __builtin_amdgcn_exp2f(a * a * -1.4426950408889634f);
+  return copysignf(fmaf(-p, e, 1.0f), x);
+}
+
+template <int ACT> __device__ __forceinline__ float act_fn(float x) {
+  if (ACT == ACT_RELU) return fmaxf(x, 0.0f);
+  if (ACT == ACT_GELU) { const float h = 0.5f * x; return fmaf(h, erf_fast(x * 0.70710678118654752440f), h); }
+  if (ACT == ACT_LEAKY) return fmaxf(x, 0.0f) + 0.01f * fminf(x, 0.0f);
+  return x;
+}
+
+// staged-row length (dwords) of the epilogue tile: BN elements + a pad that makes the 32 token rows a
+// wave writes land on distinct banks (fp32: stride = 4*odd for ds_write_b128, 16-bit: 2*odd for b64)
+template <int BN, bool F32> struct StageRow { static constexpr int dwords = F32 ? BN + 4 : BN / 2 + 2; };
+
+template <typename T, int BM, int BN, int BKB, int EPI> struct GemmSmem {
+  static constexpr bool kStageF32 = (sizeof(T) == 4) || EPI == EPI_RESID || EPI == EPI_SPLITK;
+  static constexpr int kMain = 2 * (BM + BN) * BKB;
+  static constexpr int kEpi = BM * StageRow<BN, kStageF32>::dwords * 4;
+  static constexpr int bytes = kMain > kEpi ? kMain : kEpi;
+};
+
+template <typename T, int BM, int BN, int WM, int WN, int BKB, int AMODE, int EPI, int ACT>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   constexpr int EPC = DT<T>::EPC;
-  constexpr int BKB = (sizeof(T) == 4) ? 64 : 128;   // bytes of K per LDS row
-  constexpr int CPR = BKB / 16;                      // 16-byte chunks per row
-  constexpr int BK = CPR * EPC;                      // K elements per tile (16 fp32 / 64 16-bit)
+  constexpr int CPR = BKB / 16;                      // 16-byte chunks per LDS row
+  constexpr int BK = CPR * EPC;                      // K elements per tile
   constexpr int SW_SHIFT = (CPR == 4) ? 2 : 1;
   constexpr int WAVES_N = BN / WN;
   static_assert((BM / WM) * WAVES_N == 4, "4 waves per workgroup");
+  static_assert(BKB == 64 || BKB == 128, "LDS rows are 64 or 128 bytes");
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int A_CH = BM * CPR, B_CH = BN * CPR;
   constexpr int A_SLOTS = (A_CH + 255) / 256, B_SLOTS = (B_CH + 255) / 256;
   constexpr int A_BYTES = BM * BKB, B_BYTES = BN * BKB;
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -102,7 +137,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   const T* __restrict__ Wp = (const T*)g.Wt;
 
   // ---- per-slot constants (row/chunk of each 16-byte piece this thread stages) ----
-  int a_coff[A_SLOTS];            // element offset of the chunk inside the K tile
+  int a_coff[A_SLOTS];
   bool a_ok[A_SLOTS];
   int64_t a_base[A_SLOTS];        // PLAIN: row*lda ; im2col: image base (b*H*W)
   int a_y[A_SLOTS], a_x[A_SLOTS]; // im2col: conv-output coordinates
@@ -118,9 +153,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
       a_base[s] = (int64_t)m * g.lda;
     } else if (AMODE == A_IM2COL3_POOL) {
       // m = ((b*Hp + yo)*Wp + xo)*4 + (dy*2+dx): 4 consecutive rows = one 2x2 pool window
-      const int Hp = g.H >> 1, Wp = g.W >> 1;
+      const int Hp = g.H >> 1, Wp2 = g.W >> 1;
       const int q = m & 3, p = m >> 2;
-      const int xo = p % Wp, t = p / Wp;
+      const int xo = p % Wp2, t = p / Wp2;
       const int yo = t % Hp, b = t / Hp;
       a_y[s] = 2 * yo + (q >> 1);
       a_x[s] = 2 * xo + (q & 1);
@@ -234,76 +269,116 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
         const int row = wn0 + j * 32 + lr;
         bf[j] = *(const u32x4*)(sB + row * BKB + ((c ^ ((row >> SW_SHIFT) & (CPR - 1))) << 4));
       }
+      // Wt fragment is the MFMA "A" operand: the accumulator then has the TOKEN on the lane and 4
+      // consecutive output channels in 4 consecutive registers (D row = channel, D col = token).
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) Mfma<T>::run(af[i], bf[j], acc[i][j]);
+        for (int j = 0; j < NI; ++j) Mfma<T>::run(bf[j], af[i], acc[i][j]);
     }
     if (kt + 1 < nkt) stage((kt + 1) & 1);
     __syncthreads();
   }
 
-  // ---- epilogue: acc[i][j][r] is C[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  T* __restrict__ Cp = (T*)g.C;
+  // ---- epilogue -----------------------------------------------------------------------------
+  // acc[i][j][r]: token  m = m0 + wm0 + 32 i + (lane & 31)
+  //               channel n = n0 + wn0 + 32 j + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  // 1) bias / activation / layer-scale in registers, 2) stage the tile in LDS as [token][channel],
+  // 3) read it back row-wise so every global store is 8-16 B per lane over contiguous channels.
+  constexpr bool STAGE_F32 = GemmSmem<T, BM, BN, BKB, EPI>::kStageF32;
+  constexpr int SROW = StageRow<BN, STAGE_F32>::dwords;       // dwords per staged row
+  uint32_t* sC = reinterpret_cast<uint32_t*>(smem);
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
+    const int ml = wm0 + i * 32 + lr;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int n = n0 + wn0 + j * 32 + lr;
-      const bool n_ok = n < g.N;
-      const int mb = m0 + wm0 + i * 32 + 4 * lh;
-      if (EPI == EPI_BIAS_ACT) {
-        const float bv = (g.bias && n_ok) ? g.bias[n] : 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + (r & 3) + 8 * (r >> 2);
-          if (n_ok && m < g.M) Cp[(int64_t)m * g.ldc + n] = from_f<T>(apply_act(acc[i][j][r] + bv, g.act));
-        }
-      } else if (EPI == EPI_RESID) {
-        const float bv = (g.bias && n_ok) ? g.bias[n] : 0.0f;
-        const float gv = n_ok ? g.gamma[n] : 0.0f;
-        const T* __restrict__ Rp = (const T*)g.resid;
+      for (int q = 0; q < 4; ++q) {
+        const int nl = wn0 + j * 32 + 8 * q + 4 * lh;
+        const int n = n0 + nl;
+        float v[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + (r & 3) + 8 * (r >> 2);
-          if (n_ok && m < g.M) {
-            const int64_t o = (int64_t)m * g.ldc + n;
-            Cp[o] = from_f<T>(to_f(Rp[o]) + gv * (acc[i][j][r] + bv));
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+        if (EPI != EPI_SPLITK) {
+          f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f};
+          if (n < g.N) {
+            const int bi = (EPI == EPI_CONVT) ? (n & ((1 << g.cout_log2) - 1)) : n;
+            if (g.bias) bv = *(const f32x4*)(g.bias + bi);
+            if (EPI == EPI_RESID) gv = *(const f32x4*)(g.gamma + n);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] = act_fn<ACT>(v[e] + bv[e]);
+            if (EPI == EPI_RESID) v[e] *= gv[e];
           }
         }
-      } else if (EPI == EPI_POOL4) {
-        const float bv = (g.bias && n_ok) ? g.bias[n] : 0.0f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int m = mb + 8 * q;                      // first of 4 consecutive rows
-          float v = fmaxf(fmaxf(acc[i][j][4 * q], acc[i][j][4 * q + 1]),
-                          fmaxf(acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]));
-          v = apply_act(v + bv, g.act);                  // act is monotone (ReLU): max commutes
-          if (n_ok && m < g.M) Cp[(int64_t)(m >> 2) * g.ldc + n] = from_f<T>(v);
-        }
-      } else if (EPI == EPI_CONVT) {
-        const int cout = 1 << g.cout_log2;
-        const int co = n & (cout - 1), dq = n >> g.cout_log2;
-        const int dy = dq >> 1, dx = dq & 1;
-        const float bv = (g.bias && n_ok) ? g.bias[co] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + (r & 3) + 8 * (r >> 2);
-          if (n_ok && m < g.M) {
-            const int x = m % g.W, t = m / g.W;
-            const int y = t % g.H, b = t / g.H;
-            const int64_t o = ((((int64_t)b * 2 * g.H + 2 * y + dy) * 2 * g.W + 2 * x + dx) << g.cout_log2) + co;
-            Cp[o] = from_f<T>(apply_act(acc[i][j][r] + bv, g.act));
-          }
-        }
-      } else {  // EPI_SPLITK
-        float* __restrict__ Pp = g.partial + (int64_t)blockIdx.y * g.M * g.N;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + (r & 3) + 8 * (r >> 2);
-          if (n_ok && m < g.M) Pp[(int64_t)m * g.N + n] = acc[i][j][r];
+        if (STAGE_F32) {
+          f32x4 o = {v[0], v[1], v[2], v[3]};
+          *(f32x4*)(sC + ml * SROW + nl) = o;
+        } else {
+          typedef T t4 __attribute__((ext_vector_type(4)));
+          t4 o = {from_f<T>(v[0]), from_f<T>(v[1]), from_f<T>(v[2]), from_f<T>(v[3])};
+          *(t4*)(sC + ml * SROW + (nl >> 1)) = o;
         }
       }
+    }
+  }
+  __syncthreads();
+
+  constexpr int PPR = BN / 4;                       // 4-channel pieces per row
+  constexpr int ROWS = (EPI == EPI_POOL4) ? BM / 4 : BM;
+  typedef T t4 __attribute__((ext_vector_type(4)));
+  T* Cp = (T*)g.C;
+  for (int idx = tid; idx < ROWS * PPR; idx += 256) {
+    const int rl = idx / PPR, pc = idx - rl * PPR;
+    const int n = n0 + 4 * pc;
+    const int m = m0 + ((EPI == EPI_POOL4) ? 4 * rl : rl);
+    if (m >= g.M || n >= g.N) continue;
+    f32x4 v;
+    if (EPI == EPI_POOL4) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f32x4 w;
+        if (STAGE_F32) {
+          w = *(const f32x4*)(sC + (4 * rl + k) * SROW + 4 * pc);
+        } else {
+          const t4 h = *(const t4*)(sC + (4 * rl + k) * SROW + 2 * pc);
+          w = f32x4{to_f(h[0]), to_f(h[1]), to_f(h[2]), to_f(h[3])};
+        }
+        if (k == 0) v = w;
+        else
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], w[e]);
+      }
+    } else if (STAGE_F32) {
+      v = *(const f32x4*)(sC + rl * SROW + 4 * pc);
+    }
+    int64_t o;
+    if (EPI == EPI_CONVT) {
+      const int xx = m % g.W, tt = m / g.W;
+      const int yy = tt % g.H, bb = tt / g.H;
+      const int dq = n >> g.cout_log2, co = n & ((1 << g.cout_log2) - 1);
+      o = ((((int64_t)bb * 2 * g.H + 2 * yy + (dq >> 1)) * 2 * g.W + 2 * xx + (dq & 1)) << g.cout_log2) + co;
+    } else if (EPI == EPI_POOL4) {
+      o = (int64_t)(m >> 2) * g.ldc + n;
+    } else {
+      o = (int64_t)m * g.ldc + n;
+    }
+    if (EPI == EPI_SPLITK) {
+      *(f32x4*)(g.partial + ((int64_t)blockIdx.y * g.M + m) * g.N + n) = v;
+      continue;
+    }
+    if (EPI == EPI_RESID) {
+      const t4 r = *(const t4*)((const T*)g.resid + o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += to_f(r[e]);
+    }
+    if (STAGE_F32 || EPI == EPI_POOL4) {
+      t4 out = {from_f<T>(v[0]), from_f<T>(v[1]), from_f<T>(v[2]), from_f<T>(v[3])};
+      *(t4*)(Cp + o) = out;
+    } else {
+      *(t4*)(Cp + o) = *(const t4*)(sC + rl * SROW + 2 * pc);
     }
   }
 }
