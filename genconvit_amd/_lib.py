@@ -71,6 +71,11 @@ SIGNATURES = {
     "gcv_k_reparam": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gcv_k_head_tail": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gcv_k_resize_mse": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "gcv_k_swin_window_attn": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                       c_void_p]),
+    "gcv_k_patch_merge_ln": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                     c_void_p]),
+    "gcv_k_mean_tokens": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
 }
 
 _lib = None

@@ -241,4 +241,18 @@ int gcv_k_resize_mse(int dtype, const void* xhat, const void* img, void* recon, 
   DISPATCH_DT(dtype, launch_resize_mse<T>((const T*)xhat, (const T*)img, (T*)recon, msepart, mse, B, (hipStream_t)s));
 }
 
+int gcv_k_swin_window_attn(int dtype, const void* qkv, const float* rpb, void* out, int nimg, int H, int W, int C,
+                           int nH, int shift, gcv_stream s) {
+  DISPATCH_DT(dtype, launch_swin_window_attn<T>((const T*)qkv, rpb, (T*)out, nimg, H, W, C, nH, shift, (hipStream_t)s));
+}
+
+int gcv_k_patch_merge_ln(int dtype, const void* x, const float* w, const float* b, void* out, int nimg, int H, int W,
+                         int C, float eps, gcv_stream s) {
+  DISPATCH_DT(dtype, launch_patch_merge_ln<T>((const T*)x, w, b, (T*)out, nimg, H, W, C, eps, (hipStream_t)s));
+}
+
+int gcv_k_mean_tokens(int dtype, const void* x, void* out, int nimg, int L, int C, gcv_stream s) {
+  DISPATCH_DT(dtype, launch_mean_tokens<T>((const T*)x, (T*)out, nimg, L, C, (hipStream_t)s));
+}
+
 }  // extern "C"

@@ -81,6 +81,13 @@ const char* get_error();
     }                                                                               \
   } while (0)
 
+#define GCV_TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+#define GCV_UP(dst, store, vec)                                                     \
+  do {                                                                              \
+    dst = (store).upload(vec);                                                      \
+    if (!(dst)) { ::gcv::set_error("hipMalloc/upload failed for " #dst); return -5; } \
+  } while (0)
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

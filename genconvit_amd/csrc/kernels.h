@@ -39,6 +39,11 @@ template <typename T> int launch_head_tail(const T* h, const float* w, const flo
                                            hipStream_t s);
 template <typename T> int launch_resize_mse(const T* xhat, const T* img, T* recon, float* msepart, float* mse, int B,
                                             hipStream_t s);
+template <typename T> int launch_swin_window_attn(const T* qkv, const float* rpb, T* out, int nimg, int H, int W, int C,
+                                                  int nH, int shift, hipStream_t s);
+template <typename T> int launch_patch_merge_ln(const T* x, const float* w, const float* b, T* out, int nimg, int H,
+                                                int W, int C, float eps, hipStream_t s);
+template <typename T> int launch_mean_tokens(const T* x, T* out, int nimg, int L, int C, hipStream_t s);
 int launch_kl(const float* partial, int splitk, const float* bias, const float* mu, float* rowsum, float* kl, int B,
               int N, hipStream_t s);
 int launch_vote(const float* logits, int rows, float* mean2, hipStream_t s);

@@ -286,6 +286,142 @@ __global__ void __launch_bounds__(256) layernorm_rows_kernel(const T* __restrict
   }
 }
 
+// ------------------------------------------------------------------ K16: Swin window attention
+// One wave per (window, head): 49 tokens x head_dim 32.  K and V of the window are staged in LDS as
+// fp32; lane i < 49 owns query row i: scores against the 49 keys (+ relative-position bias looked up
+// from the (169, nH) table, + the -100 shift mask between regions), fp32 softmax in registers, then
+// P.V.  The cyclic shift and the window partition are index arithmetic on the (B,H,W,3C) qkv tensor;
+// the result is written back at the token's original position (reverse shift folded in).
+template <typename T>
+__global__ void __launch_bounds__(64) swin_window_attn_kernel(const T* __restrict__ qkv, const float* __restrict__ rpb,
+                                                              T* __restrict__ out, int H, int W, int C, int nH,
+                                                              int shift, float scale) {
+  __shared__ __attribute__((aligned(16))) float sK[49 * 32];
+  __shared__ __attribute__((aligned(16))) float sV[49 * 32];
+  const int lane = threadIdx.x;
+  const int head = blockIdx.y;
+  const int nWx = W / 7, nWy = H / 7;
+  const int win = blockIdx.x % (nWx * nWy);
+  const int b = blockIdx.x / (nWx * nWy);
+  const int wy = win / nWx, wx = win - wy * nWx;
+  const bool live = lane < 49;
+  const int ty = live ? lane / 7 : 0, tx = live ? lane - (lane / 7) * 7 : 0;
+  const int ys = wy * 7 + ty, xs = wx * 7 + tx;                    // coordinates in the shifted frame
+  const int yo = (ys + shift) % H, xo = (xs + shift) % W;          // original position of that token
+  const int64_t tok = ((int64_t)b * H + yo) * W + xo;
+  const T* base = qkv + tok * 3 * C + head * 32;
+  float q[32];
+  if (live) {
+#pragma unroll
+    for (int d = 0; d < 32; ++d) {
+      q[d] = to_f(base[d]) * scale;
+      sK[lane * 32 + d] = to_f(base[C + d]);
+      sV[lane * 32 + d] = to_f(base[2 * C + d]);
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < 32; ++d) q[d] = 0.0f;
+  }
+  __syncthreads();
+  // region id of this token for the shift mask (timm: slices (0,-ws), (-ws,-shift), (-shift,None))
+  const int ry = ys < H - 7 ? 0 : (ys < H - shift ? 1 : 2);
+  const int rx = xs < W - 7 ? 0 : (xs < W - shift ? 1 : 2);
+  const int myreg = ry * 3 + rx;
+  float sc[49];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < 49; ++j) {
+    const int jy = j / 7, jx = j % 7;
+    float a = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) a = fmaf(q[d], sK[j * 32 + d], a);
+    const int ridx = (ty - jy + 6) * 13 + (tx - jx + 6);
+    a += rpb[ridx * nH + head];
+    if (shift) {
+      const int ysj = wy * 7 + jy, xsj = wx * 7 + jx;
+      const int rj = (ysj < H - 7 ? 0 : (ysj < H - shift ? 1 : 2)) * 3 + (xsj < W - 7 ? 0 : (xsj < W - shift ? 1 : 2));
+      if (rj != myreg) a -= 100.0f;
+    }
+    sc[j] = a;
+    mx = fmaxf(mx, a);
+  }
+  float sum = 0.0f;
+  float o[32];
+#pragma unroll
+  for (int d = 0; d < 32; ++d) o[d] = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 49; ++j) {
+    const float p = __expf(sc[j] - mx);
+    sum += p;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = fmaf(p, sV[j * 32 + d], o[d]);
+  }
+  if (live) {
+    const float inv = 1.0f / sum;
+    T* dst = out + tok * C + head * 32;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) dst[d] = from_f<T>(o[d] * inv);
+  }
+}
+
+// ------------------------------------------------------------------ Swin PatchMerging front half
+// x (n,H,W,C) -> LN over the 4C concat [x(0::2,0::2), x(1::2,0::2), x(0::2,1::2), x(1::2,1::2)] -> (n,H/2,W/2,4C)
+template <typename T>
+__global__ void __launch_bounds__(256) patch_merge_ln_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bvec, T* __restrict__ out,
+                                                             int nimg, int H, int W, int C, float eps) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int Ho = H >> 1, Wo = W >> 1;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= (int64_t)nimg * Ho * Wo) return;
+  const int xo = (int)(row % Wo);
+  const int64_t t = row / Wo;
+  const int yo = (int)(t % Ho);
+  const int64_t b = t / Ho;
+  const int C4 = 4 * C;
+  float v[24];
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 24; ++k) {
+    const int c4 = lane + 64 * k;
+    float val = 0.0f;
+    if (c4 < C4) {
+      const int part = c4 / C, c = c4 - part * C;       // part = dx*2 + dy
+      const int dy = part & 1, dx = part >> 1;
+      val = to_f(x[((b * H + 2 * yo + dy) * W + 2 * xo + dx) * C + c]);
+    }
+    v[k] = val;
+    s += val;
+  }
+  s = wave_sum(s);
+  const float mean = s / (float)C4;
+  float q = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 24; ++k) {
+    const float d = (lane + 64 * k < C4) ? v[k] - mean : 0.0f;
+    q = fmaf(d, d, q);
+  }
+  q = wave_sum(q);
+  const float rstd = 1.0f / sqrtf(q / (float)C4 + eps);
+  T* dst = out + row * C4;
+#pragma unroll
+  for (int k = 0; k < 24; ++k) {
+    const int c4 = lane + 64 * k;
+    if (c4 < C4) dst[c4] = from_f<T>((v[k] - mean) * rstd * w[c4] + bvec[c4]);
+  }
+}
+
+// mean over the L tokens of each image: x (n, L, C) -> (n, C)
+template <typename T>
+__global__ void __launch_bounds__(256) mean_tokens_kernel(const T* __restrict__ x, T* __restrict__ out, int L, int C) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.0f;
+    for (int p = 0; p < L; ++p) s += to_f(x[((int64_t)b * L + p) * C + c]);
+    out[(int64_t)b * C + c] = from_f<T>(s / (float)L);
+  }
+}
+
 // ------------------------------------------------------------------ K7: avg-pool + LN(768)
 template <typename T>
 __global__ void __launch_bounds__(256) pool_ln_kernel(const T* __restrict__ x, const float* __restrict__ w,

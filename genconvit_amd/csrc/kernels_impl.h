@@ -139,6 +139,36 @@ int launch_resize_mse(const T* xhat, const T* img, T* recon, float* msepart, flo
   return 0;
 }
 
+template <typename T>
+int launch_swin_window_attn(const T* qkv, const float* rpb, T* out, int nimg, int H, int W, int C, int nH, int shift,
+                            hipStream_t s) {
+  GCV_REQUIRE(H % 7 == 0 && W % 7 == 0 && C == nH * 32 && nimg > 0, "swin attention: 7x7 windows, head_dim 32");
+  GCV_REQUIRE(shift == 0 || (shift == 3 && H > 7), "swin attention: shift is 0 or 3");
+  const float scale = 0.17677669529663689f;   // 32^-0.5
+  hipLaunchKernelGGL((swin_window_attn_kernel<T>), dim3(nimg * (H / 7) * (W / 7), nH), dim3(64), 0, s, qkv, rpb, out,
+                     H, W, C, nH, shift, scale);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int launch_patch_merge_ln(const T* x, const float* w, const float* b, T* out, int nimg, int H, int W, int C, float eps,
+                          hipStream_t s) {
+  GCV_REQUIRE(H % 2 == 0 && W % 2 == 0 && 4 * C <= 1536 && nimg > 0, "patch merging: even H, W; 4C <= 1536");
+  const int64_t rows = (int64_t)nimg * (H / 2) * (W / 2);
+  hipLaunchKernelGGL((patch_merge_ln_kernel<T>), dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, s, x, w, b, out, nimg,
+                     H, W, C, eps);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T> int launch_mean_tokens(const T* x, T* out, int nimg, int L, int C, hipStream_t s) {
+  GCV_REQUIRE(nimg > 0 && L > 0 && C > 0, "mean_tokens: empty");
+  hipLaunchKernelGGL((mean_tokens_kernel<T>), dim3(nimg), dim3(256), 0, s, x, out, L, C);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 #define GCV_INSTANTIATE_KERNELS(T)                                                                                    \
   template int launch_stem_ln<T>(const T*, int64_t, int64_t, int64_t, int64_t, const float*, const float*,            \
                                  const float*, const float*, T*, int, int, int, float, hipStream_t);                  \
@@ -152,6 +182,9 @@ int launch_resize_mse(const T* xhat, const T* img, T* recon, float* msepart, flo
   template int launch_convt2_small<T>(const T*, const float*, const float*, T*, int, int, int, int, hipStream_t);     \
   template int launch_reparam<T>(const float*, int, const float*, const float*, float*, T*, int, int, hipStream_t);   \
   template int launch_head_tail<T>(const T*, const float*, const float*, float*, int, int, hipStream_t);              \
-  template int launch_resize_mse<T>(const T*, const T*, T*, float*, float*, int, hipStream_t);
+  template int launch_resize_mse<T>(const T*, const T*, T*, float*, float*, int, hipStream_t);                        \
+  template int launch_swin_window_attn<T>(const T*, const float*, T*, int, int, int, int, int, int, hipStream_t);     \
+  template int launch_patch_merge_ln<T>(const T*, const float*, const float*, T*, int, int, int, int, float, hipStream_t); \
+  template int launch_mean_tokens<T>(const T*, T*, int, int, int, hipStream_t);
 
 }  // namespace gcv

@@ -202,8 +202,6 @@ template <typename T> struct NetImpl : NetBase {
     for (size_t i = 0; i < v.size(); ++i) o[i] = host_cvt<T>(v[i]);
     return o;
   }
-#define GCV_TRY(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
-#define GCV_UP(dst, store, vec) do { dst = (store).upload(vec); if (!(dst)) { set_error("hipMalloc/upload failed for " #dst); return -5; } } while (0)
 
   int up_f32(const TensorMap& w, const std::string& name, int64_t n, WeightStore& st, float*& dst) {
     std::vector<float> v;
@@ -437,7 +435,7 @@ template <typename T> struct NetImpl : NetBase {
     GCV_CHECK_HIP(hipSetDevice(device));
     has_swin = false;
     ws_swin.clear();
-    GCV_TRY(pack_swin<T>(w, prefix, ws_swin, swin));
+    GCV_TRY((pack_swin<T>(*this, w, prefix, swin)));
     has_swin = true;
     return 0;
   }
@@ -732,6 +730,7 @@ template <typename T> struct NetImpl : NetBase {
       GCV_TRY(check_batch(B));
     }
     cur = s;
+    if (!arena.dry) GCV_REQUIRE(xv && logits1000, "null input/output");
     return run_swin<T>(*this, swin, (const T*)xv, B, (T*)logits1000);
   }
 

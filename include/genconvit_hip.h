@@ -129,6 +129,15 @@ int gcv_k_head_tail(int dtype, const void* h, const float* w, const float* bias,
 int gcv_k_resize_mse(int dtype, const void* xhat, const void* img, void* recon, float* msepart, float* mse, int B,
                      gcv_stream s);
 
+/* Swin-T pieces (timm swin_tiny_patch4_window7_224): W-MSA / SW-MSA over 7x7
+ * windows with relative-position bias + shift mask on a (B,H,W,3C) qkv tensor; PatchMerging's
+ * 2x2 gather + LayerNorm(4C); mean over tokens. */
+int gcv_k_swin_window_attn(int dtype, const void* qkv, const float* rpb, void* out, int nimg, int H, int W, int C,
+                           int nH, int shift, gcv_stream s);
+int gcv_k_patch_merge_ln(int dtype, const void* x, const float* w, const float* b, void* out, int nimg, int H, int W,
+                         int C, float eps, gcv_stream s);
+int gcv_k_mean_tokens(int dtype, const void* x, void* out, int nimg, int L, int C, gcv_stream s);
+
 #if defined(GCV_BUILD)
 #pragma GCC visibility pop
 #endif

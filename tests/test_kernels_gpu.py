@@ -336,3 +336,57 @@ def test_errors_are_raised_not_swallowed():
     with pytest.raises(_lib.GenConViTHipError, match="C must be one of"):
         x = torch.zeros((1, 7, 7, 100), device=dev())
         kutil.call("gcv_k_dwconv7_ln", 0, ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), 1, 7, 7, 100, 1e-6)
+
+
+# ----------------------------------------------------------------------------- Swin-T pieces (row A6)
+@pytest.mark.parametrize("dt", ALL)
+@pytest.mark.parametrize("H,C,nH,shift", [(14, 96, 3, 0), (14, 96, 3, 3), (28, 192, 6, 3), (7, 768, 24, 0)])
+def test_swin_window_attention(dt, H, C, nH, shift):
+    """W-MSA / SW-MSA (timm 0.6.5 WindowAttention + cyclic shift + mask) on a (B,H,W,3C) qkv tensor."""
+    from oracle.cpu_ref import _swin_attn_mask, _swin_rel_index
+    dtype = DTYPES[dt]
+    B, ws, N = 2, 7, 49
+    qkv = q(rnd((B, H, H, 3 * C), 1, 1.5), dtype)
+    table = rnd((169, nH), 2, 0.5)
+    y = qkv
+    if shift:
+        y = torch.roll(y, shifts=(-shift, -shift), dims=(1, 2))
+    yw = y.view(B, H // ws, ws, H // ws, ws, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(-1, N, 3, nH, C // nH)
+    qq, kk, vv = yw.permute(2, 0, 3, 1, 4).unbind(0)
+    attn = (qq * (C // nH) ** -0.5) @ kk.transpose(-2, -1)
+    attn = attn + table[_swin_rel_index(ws).view(-1)].view(N, N, nH).permute(2, 0, 1).unsqueeze(0)
+    if shift:
+        m = _swin_attn_mask(H, H, ws, shift)
+        attn = (attn.view(B, m.shape[0], nH, N, N) + m.unsqueeze(1).unsqueeze(0)).view(-1, nH, N, N)
+    o = (attn.softmax(-1) @ vv).transpose(1, 2).reshape(-1, N, C)
+    o = o.view(B, H // ws, H // ws, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H, H, C)
+    if shift:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    out = torch.zeros((B, H, H, C), dtype=dtype, device=dev())
+    kutil.call("gcv_k_swin_window_attn", _lib.dtype_code(dtype), ptr(D(qkv, dtype)), ptr(D(table)), ptr(out), B, H, H, C,
+               nH, shift)
+    assert_close(out, o, tol(dtype, 2.0), "window attention")
+
+
+@pytest.mark.parametrize("dt", ALL)
+@pytest.mark.parametrize("C,H", [(96, 56), (192, 28), (384, 14)])
+def test_swin_patch_merging_layernorm(dt, C, H):
+    dtype = DTYPES[dt]
+    n = 2
+    x = q(rnd((n, H, H, C), 1, 2.0), dtype)
+    lw, lb = rnd((4 * C,), 4, 0.5) + 1.0, rnd((4 * C,), 5, 0.1)
+    y = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)
+    want = F.layer_norm(y, (4 * C,), lw, lb, 1e-5)
+    out = torch.zeros((n, H // 2, H // 2, 4 * C), dtype=dtype, device=dev())
+    kutil.call("gcv_k_patch_merge_ln", _lib.dtype_code(dtype), ptr(D(x, dtype)), ptr(D(lw)), ptr(D(lb)), ptr(out), n, H,
+               H, C, 1e-5)
+    assert_close(out, want, tol(dtype, 3.0), "patch merging")
+
+
+@pytest.mark.parametrize("dt", ALL)
+def test_mean_over_tokens(dt):
+    dtype = DTYPES[dt]
+    x = q(rnd((3, 49, 768), 1, 2.0), dtype)
+    out = torch.zeros((3, 768), dtype=dtype, device=dev())
+    kutil.call("gcv_k_mean_tokens", _lib.dtype_code(dtype), ptr(D(x, dtype)), ptr(out), 3, 49, 768)
+    assert_close(out, x.mean(1), tol(dtype, 1.0), "mean tokens")
