@@ -465,16 +465,25 @@ __global__ void __launch_bounds__(256) conv3_first_kernel(const T* __restrict__ 
                                                           int64_t sx, const float* __restrict__ wp,
                                                           const float* __restrict__ bias, T* __restrict__ out,
                                                           int nimg, int H, int W, int act) {
+  // 27x16 taps live in LDS and are read as wave-uniform (broadcast) float4s (in SGPRs they overflowed
+  // the scalar file: the spill code ran at 3 % of the VALU rate).  The thread's input patch is parked in
+  // LDS as [element][thread] so the 27-tap loop can stay a real loop: fully unrolled, hipcc hoists all
+  // 432 weight reads ahead of the FMAs and the kernel needs 480 VGPRs.
+  constexpr int PW = POOL ? 4 : 3;      // input patch width/height
+  constexpr int NPOS = POOL ? 4 : 1;
+  __shared__ __attribute__((aligned(16))) float sW[27 * 16];
+  __shared__ float sIn[PW * PW * 3][256];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 27 * 16; i += 256) sW[i] = wp[i];
   const int Ho = H >> 1, Wo = W >> 1;
   const int64_t total = (int64_t)nimg * Ho * Wo;
-  const int64_t gp = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (gp >= total) return;
-  const int xo = (int)(gp % Wo);
-  const int64_t t = gp / Wo;
+  const int64_t gp = (int64_t)blockIdx.x * 256 + tid;
+  const bool live = gp < total;
+  const int64_t gpc = live ? gp : total - 1;
+  const int xo = (int)(gpc % Wo);
+  const int64_t t = gpc / Wo;
   const int yo = (int)(t % Ho);
   const int64_t b = t / Ho;
-  constexpr int PW = POOL ? 4 : 3;      // input patch width/height
-  float in[PW][PW][3];
   const int iy0 = 2 * yo - 1, ix0 = 2 * xo - 1;
 #pragma unroll
   for (int r = 0; r < PW; ++r)
@@ -484,33 +493,41 @@ __global__ void __launch_bounds__(256) conv3_first_kernel(const T* __restrict__ 
       const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
 #pragma unroll
       for (int ci = 0; ci < 3; ++ci)
-        in[r][s][ci] = ok ? to_f(x[b * sb + ci * sc + (int64_t)iy * sy + (int64_t)ix * sx]) : 0.0f;
+        sIn[(r * PW + s) * 3 + ci][tid] = ok ? to_f(x[b * sb + ci * sc + (int64_t)iy * sy + (int64_t)ix * sx]) : 0.0f;
     }
-  float res[16];
-  constexpr int NPOS = POOL ? 4 : 1;
+  __syncthreads();
+  float acc[NPOS][16];
 #pragma unroll
-  for (int q = 0; q < NPOS; ++q) {
-    const int dy = q >> 1, dx = q & 1;
-    float acc[16];
+  for (int q = 0; q < NPOS; ++q)
 #pragma unroll
-    for (int co = 0; co < 16; ++co) acc[co] = 0.0f;
+    for (int co = 0; co < 16; ++co) acc[q][co] = 0.0f;
+#pragma unroll 1
+  for (int k = 0; k < 27; ++k) {          // k = (ky*3 + kx)*3 + ci
+    const int tap = k / 3, ci = k - tap * 3;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const float4* wr = reinterpret_cast<const float4*>(sW + k * 16);
+    float w[16];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const float4 v4 = wr[g4];
+      w[4 * g4] = v4.x; w[4 * g4 + 1] = v4.y; w[4 * g4 + 2] = v4.z; w[4 * g4 + 3] = v4.w;
+    }
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx)
+    for (int q = 0; q < NPOS; ++q) {
+      const float v = sIn[(((q >> 1) + ky) * PW + (q & 1) + kx) * 3 + ci][tid];
 #pragma unroll
-        for (int ci = 0; ci < 3; ++ci) {
-          const float v = in[dy + ky][dx + kx][ci];
-          const float* wr = wp + ((ky * 3 + kx) * 3 + ci) * 16;
-#pragma unroll
-          for (int co = 0; co < 16; ++co) acc[co] = fmaf(v, wr[co], acc[co]);
-        }
-#pragma unroll
-    for (int co = 0; co < 16; ++co) res[co] = (q == 0) ? acc[co] : fmaxf(res[co], acc[co]);
+      for (int co = 0; co < 16; ++co) acc[q][co] = fmaf(v, w[co], acc[q][co]);
+    }
   }
+  if (!live) return;
   T* o = out + gp * 16;
 #pragma unroll
-  for (int co = 0; co < 16; ++co) o[co] = from_f<T>(apply_act(res[co] + bias[co], act));
+  for (int co = 0; co < 16; ++co) {
+    float r = acc[0][co];
+#pragma unroll
+    for (int q = 1; q < NPOS; ++q) r = fmaxf(r, acc[q][co]);
+    o[co] = from_f<T>(apply_act(r + bias[co], act));
+  }
 }
 
 // ------------------------------------------------------------------ K2/K12 last ConvTranspose2d 16 -> 3
@@ -519,6 +536,9 @@ template <typename T>
 __global__ void __launch_bounds__(256) convt2_small_kernel(const T* __restrict__ x, const float* __restrict__ wp,
                                                            const float* __restrict__ bias, T* __restrict__ out,
                                                            int nimg, int H, int W, int act) {
+  __shared__ __attribute__((aligned(16))) float sW[16 * 12];
+  if (threadIdx.x < 16 * 12) sW[threadIdx.x] = wp[threadIdx.x];
+  __syncthreads();
   const int64_t total = (int64_t)nimg * H * W;
   const int64_t gp = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gp >= total) return;
@@ -526,17 +546,23 @@ __global__ void __launch_bounds__(256) convt2_small_kernel(const T* __restrict__
   const int64_t t = gp / W;
   const int yi = (int)(t % H);
   const int64_t b = t / H;
-  float v[16];
   const T* src = x + gp * 16;
-#pragma unroll
-  for (int ci = 0; ci < 16; ++ci) v[ci] = to_f(src[ci]);
   float acc[12];
 #pragma unroll
   for (int j = 0; j < 12; ++j) acc[j] = bias[j % 3];
+#pragma unroll 1
+  for (int ci = 0; ci < 16; ++ci) {     // a real loop: unrolled, hipcc keeps all 192 weights in registers
+    const float v = to_f(src[ci]);
+    const float4* wr = reinterpret_cast<const float4*>(sW + ci * 12);
 #pragma unroll
-  for (int ci = 0; ci < 16; ++ci)
-#pragma unroll
-    for (int j = 0; j < 12; ++j) acc[j] = fmaf(v[ci], wp[ci * 12 + j], acc[j]);
+    for (int g4 = 0; g4 < 3; ++g4) {
+      const float4 w4 = wr[g4];
+      acc[4 * g4] = fmaf(v, w4.x, acc[4 * g4]);
+      acc[4 * g4 + 1] = fmaf(v, w4.y, acc[4 * g4 + 1]);
+      acc[4 * g4 + 2] = fmaf(v, w4.z, acc[4 * g4 + 2]);
+      acc[4 * g4 + 3] = fmaf(v, w4.w, acc[4 * g4 + 3]);
+    }
+  }
 #pragma unroll
   for (int dy = 0; dy < 2; ++dy) {
     T* o = out + ((b * 2 * H + 2 * yi + dy) * 2 * W + 2 * xi) * 3;
