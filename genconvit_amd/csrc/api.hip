@@ -5,6 +5,7 @@
 #include <map>
 #include <sstream>
 
+#include "fused_mlp.h"
 #include "gemm.h"
 #include "kernels.h"
 #include "net.h"
@@ -253,6 +254,26 @@ int gcv_k_patch_merge_ln(int dtype, const void* x, const float* w, const float* 
 
 int gcv_k_mean_tokens(int dtype, const void* x, void* out, int nimg, int L, int C, gcv_stream s) {
   DISPATCH_DT(dtype, launch_mean_tokens<T>((const T*)x, (T*)out, nimg, L, C, (hipStream_t)s));
+}
+
+// fused ConvNeXt MLP (16-bit only): W2 is given as plain (C,4C) fp32 on the device and packed here
+int gcv_k_fused_mlp(int dtype, int C, const void* x, const void* w1, const float* b1, const float* w2_f32,
+                    const float* b2, const float* gamma, const void* resid, void* out, int M, gcv_stream s) {
+  GCV_REQUIRE(dtype == GCV_F16 || dtype == GCV_BF16, "fused MLP is built for 16-bit storage");
+  void* w2c = nullptr;
+  GCV_CHECK_HIP(hipMalloc(&w2c, (size_t)4 * C * C * 2));
+  int rc;
+  MlpArgs a{x, w1, b1, w2c, b2, gamma, resid, out, M};
+  if (dtype == GCV_F16) {
+    rc = launch_pack_w2_chunks<half_t>(w2_f32, (half_t*)w2c, C, (hipStream_t)s);
+    if (!rc) rc = launch_fused_mlp<half_t>(a, C, (hipStream_t)s);
+  } else {
+    rc = launch_pack_w2_chunks<bf16_t>(w2_f32, (bf16_t*)w2c, C, (hipStream_t)s);
+    if (!rc) rc = launch_fused_mlp<bf16_t>(a, C, (hipStream_t)s);
+  }
+  (void)hipStreamSynchronize((hipStream_t)s);
+  (void)hipFree(w2c);
+  return rc;
 }
 
 }  // extern "C"

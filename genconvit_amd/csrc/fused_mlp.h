@@ -1,0 +1,222 @@
+// Fused ConvNeXt MLP for the narrow stages (C = 96, 192), 16-bit storage:
+//     out = resid + gamma * ( W2 . GELU( W1 . x_ln + b1 ) + b2 )            (timm ConvNeXtBlock)
+// The 4C-wide hidden activation never leaves the CU: unfused, stage 0 moves 13*M*C*s bytes per block
+// (the hidden tensor is written and read back once) and is HBM-bound in 16-bit; fused it moves 3*M*C*s.
+//
+// Workgroup = 8 waves = 256 tokens, each wave owns 32 tokens for the whole kernel:
+//   * the wave's x_ln rows are loaded once, straight into MFMA B-operand fragments (registers)
+//   * the hidden dimension is walked in chunks of HC = 96: W1[chunk] (HC x C) and W2[:, chunk] (C x HC)
+//     are streamed through LDS (double buffered, register-staged, one barrier per chunk) and shared by
+//     the 8 waves
+//   * GEMM1 accumulators have the hidden index on registers and the token on the lane, so after
+//     bias + GELU (branch-free erf) they are packed to 16-bit and fed directly as the B operand of
+//     GEMM2 (guide: "an accumulator tile as the next MFMA's operand"); W2's hidden axis is
+//     pre-permuted at pack time (bits 2 and 3 of the index swapped inside every 16) so its A-operand
+//     fragments are plain 16-byte chunks
+//   * epilogue: (acc + b2) * gamma staged through LDS per wave, residual added, 8-byte coalesced stores
+// LDS rows are padded by 16 B (row stride / 16 odd) so ds_read_b128 fragment reads are conflict-free.
+#pragma once
+#include "gemm.h"
+
+namespace gcv {
+
+struct MlpArgs {
+  const void* X;       // (M, C) LayerNorm'ed dw-conv output
+  const void* W1;      // (4C, C) row-major (nn.Linear layout) — chunk ch = rows [ch*HC, (ch+1)*HC)
+  const float* b1;     // (4C)
+  const void* W2c;     // [4C/HC][C][HC] chunk-major, hidden axis permuted (pack_w2_chunks)
+  const float* b2;     // (C)
+  const float* gamma;  // (C)
+  const void* resid;   // (M, C) block input (may alias out)
+  void* out;           // (M, C)
+  int M;
+};
+
+constexpr int kMlpHC = 96;
+
+template <typename T, int C> struct MlpSmem {
+  static constexpr int kRow1 = C * (int)sizeof(T) + 16;          // W1 chunk row (C elements) + pad
+  static constexpr int kRow2 = kMlpHC * (int)sizeof(T) + 16;     // W2 chunk row (HC elements) + pad
+  static constexpr int kBuf = kMlpHC * kRow1 + C * kRow2;        // one chunk pair
+  static constexpr int kBias = 4 * C * 4;                        // b1 in LDS
+  static constexpr int kStage = 8 * 32 * (96 + 4) * 4;           // per-wave fp32 staging of 96 columns
+  static constexpr int kMain = 2 * kBuf + kBias;
+  static constexpr int bytes = kMain > kStage ? kMain : kStage;
+};
+
+template <typename T, int C>
+__global__ void __launch_bounds__(512) fused_mlp_kernel(const MlpArgs a) {
+  static_assert(sizeof(T) == 2, "fused MLP is built for 16-bit storage");
+  static_assert(C == 96 || C == 192, "fused MLP covers the C=96 and C=192 stages");
+  constexpr int HC = kMlpHC;
+  constexpr int NCH = 4 * C / HC;             // hidden chunks
+  constexpr int KP1 = C / 16;                 // k-steps of GEMM1 (K = C)
+  constexpr int NJ = HC / 32;                 // 32-wide hidden groups per chunk
+  constexpr int NO = C / 32;                  // 32-wide output-channel tiles
+  constexpr int ROW1 = MlpSmem<T, C>::kRow1, ROW2 = MlpSmem<T, C>::kRow2, BUF = MlpSmem<T, C>::kBuf;
+  constexpr int P1 = HC * C * 2 / 16;         // 16-byte pieces of a W1 chunk
+  constexpr int P2 = C * HC * 2 / 16;         // ... of a W2 chunk
+  constexpr int PCS = (P1 + P2 + 511) / 512;  // pieces per thread
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* sB1 = reinterpret_cast<float*>(smem + 2 * BUF);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int64_t m_wave = (int64_t)blockIdx.x * 256 + wave * 32;
+  const int64_t m = m_wave + lr;
+  const int64_t mc = m < a.M ? m : (int64_t)a.M - 1;      // clamp: tail rows compute garbage, store nothing
+
+  const T* __restrict__ Xp = (const T*)a.X;
+  const T* __restrict__ W1p = (const T*)a.W1;
+  const T* __restrict__ W2p = (const T*)a.W2c;
+
+  for (int i = tid; i < 4 * C; i += 512) sB1[i] = a.b1[i];
+
+  // x_ln fragments: k-step p, lane (token lr, half lh) holds k = 16p + 8lh .. +7
+  u32x4 xf[KP1];
+#pragma unroll
+  for (int p = 0; p < KP1; ++p) xf[p] = *(const u32x4*)(Xp + mc * C + 16 * p + 8 * lh);
+
+  // next chunk is fetched global -> registers -> LDS in two halves (before GEMM1 / before GEMM2) so
+  // only PCS/2 staging registers are live; the target buffer is idle during this iteration.
+  constexpr int PH = (PCS + 1) / 2;
+  u32x4 stage_reg[PH];
+  auto fetch = [&](int ch, int part) {
+    const unsigned char* g1 = (const unsigned char*)(W1p + (int64_t)ch * HC * C);
+    const unsigned char* g2 = (const unsigned char*)(W2p + (int64_t)ch * C * HC);
+#pragma unroll
+    for (int i = 0; i < PH; ++i) {
+      const int idx = tid + (part * PH + i) * 512;
+      if (idx < P1) stage_reg[i] = *(const u32x4*)(g1 + (int64_t)idx * 16);
+      else if (idx < P1 + P2) stage_reg[i] = *(const u32x4*)(g2 + (int64_t)(idx - P1) * 16);
+    }
+  };
+  auto stash = [&](int buf, int part) {
+    unsigned char* s1 = smem + buf * BUF;
+    unsigned char* s2 = s1 + HC * ROW1;
+    constexpr int RP1 = C * 2 / 16, RP2 = HC * 2 / 16;    // pieces per row
+#pragma unroll
+    for (int i = 0; i < PH; ++i) {
+      const int idx = tid + (part * PH + i) * 512;
+      if (idx < P1) {
+        const int row = idx / RP1, c = idx - row * RP1;
+        *(u32x4*)(s1 + row * ROW1 + c * 16) = stage_reg[i];
+      } else if (idx < P1 + P2) {
+        const int k = idx - P1;
+        const int row = k / RP2, c = k - row * RP2;
+        *(u32x4*)(s2 + row * ROW2 + c * 16) = stage_reg[i];
+      }
+    }
+  };
+
+  f32x16 acc2[NO];
+#pragma unroll
+  for (int o = 0; o < NO; ++o)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[o][r] = 0.0f;
+
+  fetch(0, 0);
+  stash(0, 0);
+  fetch(0, 1);
+  stash(0, 1);
+  __syncthreads();
+
+  for (int ch = 0; ch < NCH; ++ch) {
+    if (ch + 1 < NCH) fetch(ch + 1, 0);
+    const unsigned char* s1 = smem + (ch & 1) * BUF;
+    const unsigned char* s2 = s1 + HC * ROW1;
+
+    // ---- GEMM1: hidden[HC x 32 tokens] = W1[chunk] . x_ln^T --------------------------------
+    f32x16 acc1[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[j][r] = 0.0f;
+#pragma unroll
+    for (int p = 0; p < KP1; ++p) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const u32x4 w = *(const u32x4*)(s1 + (32 * j + lr) * ROW1 + (2 * p + lh) * 16);
+        Mfma<T>::run(w, xf[p], acc1[j]);
+      }
+    }
+    if (ch + 1 < NCH) {
+      stash((ch + 1) & 1, 0);
+      fetch(ch + 1, 1);
+    }
+    // ---- bias + GELU in registers, pack to 16-bit B-operand fragments, GEMM2 -----------------
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      u32x4 hf[2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *(const f32x4*)(sB1 + ch * HC + 32 * j + 8 * q + 4 * lh);
+        typedef T t4 __attribute__((ext_vector_type(4)));
+        t4 h4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h4[e] = from_f<T>(act_fn<ACT_GELU>(acc1[j][4 * q + e] + bv[e]));
+        const uint2 pk = __builtin_bit_cast(uint2, h4);
+        hf[q >> 1][2 * (q & 1)] = pk.x;
+        hf[q >> 1][2 * (q & 1) + 1] = pk.y;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+          const u32x4 w = *(const u32x4*)(s2 + (32 * o + lr) * ROW2 + (2 * (2 * j + s) + lh) * 16);
+          Mfma<T>::run(w, hf[s], acc2[o]);
+        }
+      }
+    }
+    if (ch + 1 < NCH) stash((ch + 1) & 1, 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: (acc2 + b2) * gamma -> per-wave LDS tile [32 tokens][96 cols] fp32 -> + resid -> store
+  float* sC = reinterpret_cast<float*>(smem) + wave * 32 * 100;
+  const T* Rp = (const T*)a.resid;
+  T* Op = (T*)a.out;
+#pragma unroll
+  for (int half = 0; half < NO / 3; ++half) {
+#pragma unroll
+    for (int oo = 0; oo < 3; ++oo) {
+      const int o = half * 3 + oo;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = 32 * o + 8 * q + 4 * lh;
+        const f32x4 bv = *(const f32x4*)(a.b2 + n);
+        const f32x4 gv = *(const f32x4*)(a.gamma + n);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (acc2[o][4 * q + e] + bv[e]) * gv[e];
+        *(f32x4*)(sC + lr * 100 + 32 * oo + 8 * q + 4 * lh) = v;
+      }
+    }
+    __syncthreads();
+    typedef T t4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int idx = lane + 64 * i;            // 32 rows x 24 four-channel pieces
+      const int row = idx / 24, pc = idx - row * 24;
+      const int64_t mm = m_wave + row;
+      if (mm < a.M) {
+        const f32x4 v = *(const f32x4*)(sC + row * 100 + 4 * pc);
+        const int64_t off = mm * C + half * 96 + 4 * pc;
+        const t4 r = *(const t4*)(Rp + off);
+        t4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = from_f<T>(v[e] + to_f(r[e]));
+        *(t4*)(Op + off) = o4;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T> int launch_fused_mlp(const MlpArgs& a, int C, hipStream_t s);
+// W2 (C,4C) fp32 on device -> chunk-major, hidden-permuted T (see header)
+template <typename T> int launch_pack_w2_chunks(const float* w2_dev, T* out, int C, hipStream_t s);
+
+}  // namespace gcv

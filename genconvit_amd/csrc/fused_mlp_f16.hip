@@ -1,0 +1,6 @@
+// fused ConvNeXt MLP kernel for storage dtype half_t
+#include "fused_mlp_impl.h"
+namespace gcv {
+template int launch_fused_mlp<half_t>(const MlpArgs&, int, hipStream_t);
+template int launch_pack_w2_chunks<half_t>(const float*, half_t*, int, hipStream_t);
+}

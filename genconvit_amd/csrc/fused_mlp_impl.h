@@ -1,0 +1,52 @@
+// launcher + weight packer for fused_mlp_kernel (included by fused_mlp_{f16,bf16}.hip)
+#pragma once
+#include "fused_mlp.h"
+
+namespace gcv {
+
+// W2 (C, 4C) fp32 row-major -> [4C/HC][C][HC] in T; inside every 16 hidden indices bits 2 and 3 are
+// swapped so that a lane's GEMM2 A-operand fragment (k = 16kk + 8(j>>2) + 4h + (j&3)) is one 16-byte chunk.
+template <typename T>
+__global__ void __launch_bounds__(256) pack_w2_chunks_kernel(const float* __restrict__ w2, T* __restrict__ out, int C) {
+  const int HC = kMlpHC;
+  const int64_t total = (int64_t)C * 4 * C;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int p = (int)(i % HC);
+  const int64_t t = i / HC;
+  const int o = (int)(t % C);
+  const int ch = (int)(t / C);
+  const int kk = p >> 4, h = (p >> 3) & 1, jj = p & 7;
+  const int hid = 16 * kk + 8 * (jj >> 2) + 4 * h + (jj & 3);
+  out[i] = from_f<T>(w2[(int64_t)o * 4 * C + ch * HC + hid]);
+}
+
+template <typename T> int launch_pack_w2_chunks(const float* w2_dev, T* out, int C, hipStream_t s) {
+  GCV_REQUIRE((4 * C) % kMlpHC == 0, "hidden width must be a multiple of the chunk");
+  const int64_t total = (int64_t)C * 4 * C;
+  hipLaunchKernelGGL((pack_w2_chunks_kernel<T>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, w2_dev, out, C);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T, int C> static int launch_mlp_c(const MlpArgs& a, hipStream_t s) {
+  constexpr int SMEM = MlpSmem<T, C>::bytes;
+  static bool attr_done = false;
+  if (!attr_done) {
+    GCV_CHECK_HIP(hipFuncSetAttribute((const void*)fused_mlp_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((fused_mlp_kernel<T, C>), dim3(cdiv(a.M, 256)), dim3(512), SMEM, s, a);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T> int launch_fused_mlp(const MlpArgs& a, int C, hipStream_t s) {
+  GCV_REQUIRE(a.M > 0 && a.X && a.W1 && a.W2c && a.b1 && a.b2 && a.gamma && a.resid && a.out, "fused MLP: null argument");
+  if (C == 96) return launch_mlp_c<T, 96>(a, s);
+  if (C == 192) return launch_mlp_c<T, 192>(a, s);
+  set_error("fused MLP is built for C = 96 and C = 192");
+  return -3;
+}
+
+}  // namespace gcv

@@ -9,8 +9,10 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
+#include "fused_mlp.h"
 #include "gemm.h"
 #include "kernels.h"
 #include "net.h"
@@ -91,6 +93,7 @@ __global__ void __launch_bounds__(256) pack_mu_kernel(const float* __restrict__ 
 template <typename T> struct CnxBlockW {
   float *dw_w, *dw_b, *ln_w, *ln_b, *fc1_b, *fc2_b, *gamma;
   T *fc1_w, *fc2_w;
+  T* fc2_wc;       // 16-bit, C <= 192: W2 packed for the fused MLP kernel (else null)
 };
 template <typename T> struct CnxW {
   float *stem_w, *stem_b, *stem_lnw, *stem_lnb;
@@ -147,6 +150,7 @@ template <typename T> struct NetImpl : NetBase {
   bool has_ed = false, has_vae = false, has_swin = false;
   Arena arena;
   hipStream_t cur = nullptr;
+  bool use_fused_mlp = std::getenv("GCV_NO_FUSED_MLP") == nullptr;   // A/B switch for profiling
 
   ~NetImpl() override {
     if (arena.base) (void)hipFree(arena.base);
@@ -311,6 +315,21 @@ template <typename T> struct NetImpl : NetBase {
         GCV_TRY(up_cast(w, b + "mlp.fc1.weight", (int64_t)4 * C * C, st, k.fc1_w));
         GCV_TRY(up_f32(w, b + "mlp.fc1.bias", 4 * C, st, k.fc1_b));
         GCV_TRY(up_cast(w, b + "mlp.fc2.weight", (int64_t)4 * C * C, st, k.fc2_w));
+        k.fc2_wc = nullptr;
+        if constexpr (sizeof(T) == 2) {
+          if (C <= 192) {
+            std::vector<float> v;
+            GCV_TRY(fetch(w, b + "mlp.fc2.weight", (int64_t)4 * C * C, v));
+            float* tmp = nullptr;
+            GCV_CHECK_HIP(hipMalloc((void**)&tmp, v.size() * 4));
+            GCV_CHECK_HIP(hipMemcpy(tmp, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+            k.fc2_wc = (T*)st.raw(v.size() * sizeof(T));
+            if (!k.fc2_wc) { set_error("hipMalloc failed for packed fc2"); return -5; }
+            GCV_TRY(launch_pack_w2_chunks<T>(tmp, k.fc2_wc, C, nullptr));
+            GCV_CHECK_HIP(hipDeviceSynchronize());
+            GCV_CHECK_HIP(hipFree(tmp));
+          }
+        }
         GCV_TRY(up_f32(w, b + "mlp.fc2.bias", C, st, k.fc2_b));
         GCV_TRY(up_f32(w, b + "gamma", C, st, k.gamma));
       }
@@ -505,6 +524,14 @@ template <typename T> struct NetImpl : NetBase {
             return launch_dwconv7_ln<T>(X + moff[s] * C, k.dw_w, k.dw_b, k.ln_w, k.ln_b, Y + moff[s] * C, segs[s].n,
                                         h[s], wd[s], C, 1e-6f, cur);
           }));
+        }
+        if constexpr (sizeof(T) == 2) {
+          if (k.fc2_wc && use_fused_mlp) {
+            MlpArgs ma{Y, k.fc1_w, k.fc1_b, k.fc2_wc, k.fc2_b, k.gamma, X, X, (int)M};
+            GCV_TRY(run("cnx.fused_mlp", 16.0 * M * C * (double)C, 3.0 * sizeof(T) * (double)M * C + 16.0 * C * C,
+                        [&] { return launch_fused_mlp<T>(ma, C, cur); }));
+            continue;
+          }
         }
         GemmArgs g1{};
         g1.A = Y; g1.lda = C; g1.Wt = k.fc1_w; g1.C = Hd; g1.ldc = 4 * C; g1.bias = k.fc1_b;

@@ -138,6 +138,12 @@ int gcv_k_patch_merge_ln(int dtype, const void* x, const float* w, const float* 
                          int C, float eps, gcv_stream s);
 int gcv_k_mean_tokens(int dtype, const void* x, void* out, int nimg, int L, int C, gcv_stream s);
 
+/* Fused ConvNeXt MLP for C = 96 / 192, 16-bit storage:
+ * out = resid + gamma * (W2 . GELU(W1 . x + b1) + b2) with the 4C hidden activation kept on chip
+ * (timm ConvNeXtBlock: mlp.fc1 -> GELU -> mlp.fc2 -> * gamma -> + shortcut).  w2_f32: (C,4C) fp32 device. */
+int gcv_k_fused_mlp(int dtype, int C, const void* x, const void* w1, const float* b1, const float* w2_f32,
+                    const float* b2, const float* gamma, const void* resid, void* out, int M, gcv_stream s);
+
 #if defined(GCV_BUILD)
 #pragma GCC visibility pop
 #endif

@@ -390,3 +390,22 @@ def test_mean_over_tokens(dt):
     out = torch.zeros((3, 768), dtype=dtype, device=dev())
     kutil.call("gcv_k_mean_tokens", _lib.dtype_code(dtype), ptr(D(x, dtype)), ptr(out), 3, 49, 768)
     assert_close(out, x.mean(1), tol(dtype, 1.0), "mean tokens")
+
+
+# ----------------------------------------------------------------------------- fused ConvNeXt MLP
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("C,M", [(96, 256), (96, 1000), (192, 300), (192, 37)])
+def test_fused_mlp_layerscale_residual(dt, C, M):
+    """timm ConvNeXtBlock tail: fc1 -> exact GELU -> fc2 -> * gamma -> + shortcut, hidden kept on chip."""
+    dtype = DTYPES[dt]
+    x = q(rnd((M, C), 1, 1.5), dtype)
+    w1 = q(rnd((4 * C, C), 2, 1 / math.sqrt(C)), dtype)
+    w2 = q(rnd((C, 4 * C), 3, 1 / math.sqrt(4 * C)), dtype)
+    b1, b2, gamma = rnd((4 * C,), 4, 0.1), rnd((C,), 5, 0.1), rnd((C,), 6, 0.5)
+    res = q(rnd((M, C), 7), dtype)
+    h = q(F.gelu(x @ w1.t() + b1), dtype)          # the kernel rounds the hidden activation to T for GEMM2
+    want = res + gamma * (h @ w2.t() + b2)
+    out = D(res, dtype).clone()
+    kutil.call("gcv_k_fused_mlp", _lib.dtype_code(dtype), C, ptr(D(x, dtype)), ptr(D(w1, dtype)), ptr(D(b1)),
+               ptr(D(w2)), ptr(D(b2)), ptr(D(gamma)), ptr(out), ptr(out), M)
+    assert_close(out, want, tol(dtype, 2.0), "fused mlp")
