@@ -40,6 +40,8 @@ __device__ __forceinline__ float apply_act(float x, int act) {
   }
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 // ---- 16-byte vector helpers ------------------------------------------------
 struct alignas(16) Chunk { uint32_t w[4]; };
 

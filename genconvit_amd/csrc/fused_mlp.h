@@ -34,18 +34,18 @@ struct MlpArgs {
 
 constexpr int kMlpHC = 96;
 
-template <typename T, int C> struct MlpSmem {
+template <typename T, int C, int NW> struct MlpSmem {
   static constexpr int kRow1 = C * (int)sizeof(T) + 16;          // W1 chunk row (C elements) + pad
   static constexpr int kRow2 = kMlpHC * (int)sizeof(T) + 16;     // W2 chunk row (HC elements) + pad
   static constexpr int kBuf = kMlpHC * kRow1 + C * kRow2;        // one chunk pair
   static constexpr int kBias = 4 * C * 4;                        // b1 in LDS
-  static constexpr int kStage = 8 * 32 * (96 + 4) * 4;           // per-wave fp32 staging of 96 columns
+  static constexpr int kStage = NW * 32 * (96 + 4) * 4;          // per-wave fp32 staging of 96 columns
   static constexpr int kMain = 2 * kBuf + kBias;
   static constexpr int bytes = kMain > kStage ? kMain : kStage;
 };
 
-template <typename T, int C>
-__global__ void __launch_bounds__(512) fused_mlp_kernel(const MlpArgs a) {
+template <typename T, int C, int NW>
+__global__ void __launch_bounds__(NW * 64) fused_mlp_kernel(const MlpArgs a) {
   static_assert(sizeof(T) == 2, "fused MLP is built for 16-bit storage");
   static_assert(C == 96 || C == 192, "fused MLP covers the C=96 and C=192 stages");
   constexpr int HC = kMlpHC;
@@ -53,10 +53,11 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(const MlpArgs a) {
   constexpr int KP1 = C / 16;                 // k-steps of GEMM1 (K = C)
   constexpr int NJ = HC / 32;                 // 32-wide hidden groups per chunk
   constexpr int NO = C / 32;                  // 32-wide output-channel tiles
-  constexpr int ROW1 = MlpSmem<T, C>::kRow1, ROW2 = MlpSmem<T, C>::kRow2, BUF = MlpSmem<T, C>::kBuf;
+  constexpr int NT = NW * 64;                 // threads
+  constexpr int ROW1 = MlpSmem<T, C, NW>::kRow1, ROW2 = MlpSmem<T, C, NW>::kRow2, BUF = MlpSmem<T, C, NW>::kBuf;
   constexpr int P1 = HC * C * 2 / 16;         // 16-byte pieces of a W1 chunk
   constexpr int P2 = C * HC * 2 / 16;         // ... of a W2 chunk
-  constexpr int PCS = (P1 + P2 + 511) / 512;  // pieces per thread
+  constexpr int PCS = (P1 + P2 + NT - 1) / NT;  // pieces per thread
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sB1 = reinterpret_cast<float*>(smem + 2 * BUF);
@@ -64,7 +65,7 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(const MlpArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
-  const int64_t m_wave = (int64_t)blockIdx.x * 256 + wave * 32;
+  const int64_t m_wave = (int64_t)blockIdx.x * (NW * 32) + wave * 32;
   const int64_t m = m_wave + lr;
   const int64_t mc = m < a.M ? m : (int64_t)a.M - 1;      // clamp: tail rows compute garbage, store nothing
 
@@ -72,23 +73,25 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(const MlpArgs a) {
   const T* __restrict__ W1p = (const T*)a.W1;
   const T* __restrict__ W2p = (const T*)a.W2c;
 
-  for (int i = tid; i < 4 * C; i += 512) sB1[i] = a.b1[i];
+  for (int i = tid; i < 4 * C; i += NT) sB1[i] = a.b1[i];
 
   // x_ln fragments: k-step p, lane (token lr, half lh) holds k = 16p + 8lh .. +7
   u32x4 xf[KP1];
 #pragma unroll
   for (int p = 0; p < KP1; ++p) xf[p] = *(const u32x4*)(Xp + mc * C + 16 * p + 8 * lh);
 
-  // next chunk is fetched global -> registers -> LDS in two halves (before GEMM1 / before GEMM2) so
-  // only PCS/2 staging registers are live; the target buffer is idle during this iteration.
-  constexpr int PH = (PCS + 1) / 2;
+  // The next chunk is fetched global -> registers at the top of an iteration and written to the idle
+  // LDS buffer at its end, so a whole iteration of MFMA + GELU covers the load latency.  SPLIT (C=192,
+  // register pressure) fetches in two halves: before GEMM1 / before GEMM2.
+  constexpr bool SPLIT = (C == 192);
+  constexpr int PH = SPLIT ? (PCS + 1) / 2 : PCS;
   u32x4 stage_reg[PH];
   auto fetch = [&](int ch, int part) {
     const unsigned char* g1 = (const unsigned char*)(W1p + (int64_t)ch * HC * C);
     const unsigned char* g2 = (const unsigned char*)(W2p + (int64_t)ch * C * HC);
 #pragma unroll
     for (int i = 0; i < PH; ++i) {
-      const int idx = tid + (part * PH + i) * 512;
+      const int idx = tid + (part * PH + i) * NT;
       if (idx < P1) stage_reg[i] = *(const u32x4*)(g1 + (int64_t)idx * 16);
       else if (idx < P1 + P2) stage_reg[i] = *(const u32x4*)(g2 + (int64_t)(idx - P1) * 16);
     }
@@ -99,7 +102,7 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(const MlpArgs a) {
     constexpr int RP1 = C * 2 / 16, RP2 = HC * 2 / 16;    // pieces per row
 #pragma unroll
     for (int i = 0; i < PH; ++i) {
-      const int idx = tid + (part * PH + i) * 512;
+      const int idx = tid + (part * PH + i) * NT;
       if (idx < P1) {
         const int row = idx / RP1, c = idx - row * RP1;
         *(u32x4*)(s1 + row * ROW1 + c * 16) = stage_reg[i];
@@ -119,8 +122,10 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(const MlpArgs a) {
 
   fetch(0, 0);
   stash(0, 0);
-  fetch(0, 1);
-  stash(0, 1);
+  if (SPLIT) {
+    fetch(0, 1);
+    stash(0, 1);
+  }
   __syncthreads();
 
   for (int ch = 0; ch < NCH; ++ch) {
@@ -142,7 +147,7 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(const MlpArgs a) {
         Mfma<T>::run(w, xf[p], acc1[j]);
       }
     }
-    if (ch + 1 < NCH) {
+    if (SPLIT && ch + 1 < NCH) {
       stash((ch + 1) & 1, 0);
       fetch(ch + 1, 1);
     }
@@ -170,7 +175,7 @@ __global__ void __launch_bounds__(512) fused_mlp_kernel(const MlpArgs a) {
         }
       }
     }
-    if (ch + 1 < NCH) stash((ch + 1) & 1, 1);
+    if (ch + 1 < NCH) stash((ch + 1) & 1, SPLIT ? 1 : 0);
     __syncthreads();
   }
 

@@ -29,22 +29,24 @@ template <typename T> int launch_pack_w2_chunks(const float* w2_dev, T* out, int
   return 0;
 }
 
-template <typename T, int C> static int launch_mlp_c(const MlpArgs& a, hipStream_t s) {
-  constexpr int SMEM = MlpSmem<T, C>::bytes;
+template <typename T, int C, int NW> static int launch_mlp_c(const MlpArgs& a, hipStream_t s) {
+  constexpr int SMEM = MlpSmem<T, C, NW>::bytes;
   static bool attr_done = false;
   if (!attr_done) {
-    GCV_CHECK_HIP(hipFuncSetAttribute((const void*)fused_mlp_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    GCV_CHECK_HIP(hipFuncSetAttribute((const void*)fused_mlp_kernel<T, C, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_done = true;
   }
-  hipLaunchKernelGGL((fused_mlp_kernel<T, C>), dim3(cdiv(a.M, 256)), dim3(512), SMEM, s, a);
+  hipLaunchKernelGGL((fused_mlp_kernel<T, C, NW>), dim3(cdiv(a.M, NW * 32)), dim3(NW * 64), SMEM, s, a);
   GCV_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 template <typename T> int launch_fused_mlp(const MlpArgs& a, int C, hipStream_t s) {
   GCV_REQUIRE(a.M > 0 && a.X && a.W1 && a.W2c && a.b1 && a.b2 && a.gamma && a.resid && a.out, "fused MLP: null argument");
-  if (C == 96) return launch_mlp_c<T, 96>(a, s);
-  if (C == 192) return launch_mlp_c<T, 192>(a, s);
+  // C=96: 4-wave workgroups (81 KB LDS -> two independent workgroups per CU overlap each other's
+  // prologue / epilogue); C=192: the double-buffered chunks fill the LDS, one 8-wave workgroup per CU
+  if (C == 96) return launch_mlp_c<T, 96, 4>(a, s);
+  if (C == 192) return launch_mlp_c<T, 192, 8>(a, s);
   set_error("fused MLP is built for C = 96 and C = 192");
   return -3;
 }

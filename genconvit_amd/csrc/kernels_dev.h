@@ -205,6 +205,239 @@ dwconv7_ln_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*[49][
   }
 }
 
+// ------------------------------------------------------------------ K4 v2 (16-bit, C = 96 / 192)
+// Same math as dwconv7_ln_kernel, restructured around the memory system:
+//   1. the 13x13 halo window of the tile (all C channels) is staged in LDS with 16-byte coalesced
+//      global loads (21 independent loads per thread in flight, zero fill outside the image) instead
+//      of 169 dependent 2-byte loads per thread
+//   2. a thread still owns one channel of a 7x7 tile with taps + accumulators in registers; inputs
+//      come from LDS (lanes = consecutive channels, conflict-free).  DOT2: horizontally adjacent
+//      inputs are packed in pairs and multiplied with packed tap pairs by v_dot2c_f32_{f16,bf16}
+//      (2 MACs per instruction, fp32 accumulate; the taps are rounded to the storage dtype)
+//   3. LayerNorm statistics through LDS as before; the normalised tile is staged in LDS and written
+//      with 16-byte coalesced stores
+template <typename T> struct Dot2;
+template <> struct Dot2<half_t> {
+  typedef _Float16 v2 __attribute__((ext_vector_type(2)));
+  __device__ static __forceinline__ float run(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), c, false);
+  }
+};
+template <> struct Dot2<bf16_t> {
+  typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+  __device__ static __forceinline__ float run(uint32_t a, uint32_t b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), c, false);
+  }
+};
+
+template <typename T> __device__ __forceinline__ uint32_t bits16(float v) {
+  const T t = from_f<T>(v);
+  return (uint32_t)__builtin_bit_cast(unsigned short, t);
+}
+template <typename T> __device__ __forceinline__ float from_bits16(uint32_t u) {
+  return to_f(__builtin_bit_cast(T, (unsigned short)u));
+}
+
+template <typename T, int C, bool DOT2>
+__global__ void __launch_bounds__(192) dwconv7_ln_v2_kernel(const T* __restrict__ x, const float* __restrict__ wdw,
+                                                            const float* __restrict__ bdw,
+                                                            const float* __restrict__ lnw,
+                                                            const float* __restrict__ lnb, T* __restrict__ y,
+                                                            int nimg, int H, int W, float eps) {
+  static_assert(sizeof(T) == 2 && (C == 96 || C == 192), "v2 covers 16-bit storage, C = 96 / 192");
+  constexpr int TILES = 192 / C;
+  constexpr int NP = TILES * 49;
+  constexpr int CP = C / 8;                           // 16-byte pieces per pixel
+  constexpr int NPIECE = TILES * 169 * CP;            // 4056
+  constexpr int IN_BYTES = TILES * 169 * C * 2;       // 64896
+  constexpr int SVAL_BYTES = NP * C * 4;              // 37632
+  constexpr int STAT_OFF = SVAL_BYTES;                // [NP][2] floats
+  constexpr int OUT_OFF = (STAT_OFF + NP * 8 + 255) & ~255;
+  static_assert(OUT_OFF + NP * C * 2 <= IN_BYTES, "LDS regions must fit in the input window");
+  extern __shared__ __attribute__((aligned(16))) unsigned char dw2_lds[];
+  unsigned short* sIn = reinterpret_cast<unsigned short*>(dw2_lds);
+  float* sval = reinterpret_cast<float*>(dw2_lds);
+  float* stats = reinterpret_cast<float*>(dw2_lds + STAT_OFF);
+  unsigned short* sOut = reinterpret_cast<unsigned short*>(dw2_lds + OUT_OFF);
+
+  const int tid = threadIdx.x;
+  const int tiles_x = (W + 6) / 7, tiles_y = (H + 6) / 7;
+  const int total = nimg * tiles_x * tiles_y;
+  const int tile0 = blockIdx.x * TILES;
+
+  // ---- 1. stage the halo windows -----------------------------------------------------------
+  // batches of independent loads first, LDS stores after: a load->store loop would expose the full
+  // memory latency once per piece (hipcc does not pipeline it)
+  constexpr int NIT = (NPIECE + 191) / 192;            // 22
+  constexpr int BATCH = 11;
+  // per-slot tile origin (the runtime divisions happen once per slot, not once per piece)
+  int s_y0[TILES], s_x0[TILES];
+  int64_t s_img[TILES];
+  bool s_ok[TILES];
+#pragma unroll
+  for (int sl = 0; sl < TILES; ++sl) {
+    const int tl = tile0 + sl;
+    s_ok[sl] = tl < total;
+    const int tlc = s_ok[sl] ? tl : 0;
+    const int txx = tlc % tiles_x, t3 = tlc / tiles_x;
+    s_x0[sl] = txx * 7 - 3;
+    s_y0[sl] = (t3 % tiles_y) * 7 - 3;
+    s_img[sl] = (int64_t)(t3 / tiles_y) * H * W;
+  }
+  // 192 threads = STEP whole pixels per sweep, so a thread keeps its 16-byte column (pc) and walks the
+  // halo pixels with constant stride: (slot, row, col) are updated incrementally, no divisions.
+  constexpr int STEP = 192 / CP;                       // pixels advanced per sweep (16 or 8)
+  const int pc8 = (tid % CP) * 8;
+  int t1 = tid / CP;                                   // slot*169 + pix
+  int slot = 0, r = t1 / 13, sx = t1 - r * 13;         // t1 < 24 < 169 at start
+#pragma unroll 1
+  for (int b0 = 0; b0 < NIT; b0 += BATCH) {
+    u32x4 v[BATCH];
+    int dst[BATCH];
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i) {
+      const bool in_range = t1 < TILES * 169;
+      const int sl = (TILES == 2) ? slot : 0;
+      const int iy = s_y0[sl] + r, ix = s_x0[sl] + sx;
+      const bool ok = in_range && s_ok[sl] && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      dst[i] = in_range ? (t1 * C + pc8) : -1;
+      const int64_t off = ok ? ((s_img[sl] + (int64_t)iy * W + ix) * C + pc8) : 0;   // always a valid address
+      const u32x4 t = *(const u32x4*)(x + off);
+      const uint32_t m = ok ? 0xffffffffu : 0u;
+      v[i] = u32x4{t[0] & m, t[1] & m, t[2] & m, t[3] & m};
+      // advance STEP pixels: 16 = 13 + 3 (or 8)
+      t1 += STEP;
+      sx += STEP % 13;
+      r += STEP / 13;
+      if (sx >= 13) { sx -= 13; r += 1; }
+      if (TILES == 2 && slot == 0 && r >= 13) { r -= 13; slot = 1; }
+    }
+#pragma unroll
+    for (int i = 0; i < BATCH; ++i)
+      if (dst[i] >= 0) *(u32x4*)(sIn + dst[i]) = v[i];
+  }
+
+  const int tslot = tid / C;
+  const int c = tid - tslot * C;
+  const int tile = tile0 + tslot;
+  const bool tile_ok = tile < total;
+  const int tx = tile % tiles_x, t2 = tile / tiles_x;
+  const int ty = t2 % tiles_y, b = t2 / tiles_y;
+  const int x0 = tx * 7, y0 = ty * 7;
+
+  float acc[49];
+  const float bv = bdw[c];
+#pragma unroll
+  for (int t = 0; t < 49; ++t) acc[t] = bv;
+  __syncthreads();
+
+  // ---- 2. 7x7 depthwise taps ------------------------------------------------------------------
+  const unsigned short* sin_c = sIn + tslot * 169 * C + c;
+  if (DOT2) {
+    uint32_t w2[28];                                   // [ky][j] = (tap(ky,2j), tap(ky,2j+1)), tap(ky,7) = 0
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t lo = bits16<T>(wdw[(ky * 7 + 2 * j) * C + c]);
+        const uint32_t hi = (j < 3) ? bits16<T>(wdw[(ky * 7 + 2 * j + 1) * C + c]) : 0u;
+        w2[ky * 4 + j] = lo | (hi << 16);
+      }
+#pragma unroll
+    for (int r = 0; r < 13; ++r) {
+      uint32_t raw[14];
+#pragma unroll
+      for (int s = 0; s < 13; ++s) raw[s] = sin_c[(r * 13 + s) * C];
+      raw[13] = 0u;
+      uint32_t pp[13];
+#pragma unroll
+      for (int s = 0; s < 13; ++s) pp[s] = raw[s] | (raw[s + 1] << 16);
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        const int oy = r - ky;
+        if (oy >= 0 && oy < 7) {
+#pragma unroll
+          for (int ox = 0; ox < 7; ++ox)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[oy * 7 + ox] = Dot2<T>::run(pp[ox + 2 * j], w2[ky * 4 + j], acc[oy * 7 + ox]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    float w[49];
+#pragma unroll
+    for (int t = 0; t < 49; ++t) w[t] = wdw[t * C + c];
+#pragma unroll
+    for (int r = 0; r < 13; ++r) {
+      float v[13];
+#pragma unroll
+      for (int s = 0; s < 13; ++s) v[s] = from_bits16<T>(sin_c[(r * 13 + s) * C]);
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+        for (int sx = 0; sx < 13; ++sx)
+#pragma unroll
+          for (int kx = 0; kx < 7; ++kx) {
+            const int oy = r - ky, ox = sx - kx;
+            if (oy >= 0 && oy < 7 && ox >= 0 && ox < 7)
+              acc[oy * 7 + ox] = fmaf(v[sx], w[ky * 7 + kx], acc[oy * 7 + ox]);
+          }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();                      // everyone is done reading the input window: reuse it
+
+  // ---- 3. LayerNorm over channels ------------------------------------------------------------
+#pragma unroll
+  for (int p = 0; p < 49; ++p) sval[(tslot * 49 + p) * C + c] = acc[p];
+  __syncthreads();
+  const int grp = tid >> 5, gl = tid & 31;
+  for (int p = grp; p < NP; p += 6) {
+    const float* row = sval + p * C;
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < C / 32; ++k) s += row[gl + 32 * k];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * (1.0f / C);
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < C / 32; ++k) { const float d = row[gl + 32 * k] - mean; q = fmaf(d, d, q); }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    if (gl == 0) {
+      stats[2 * p] = mean;
+      stats[2 * p + 1] = 1.0f / sqrtf(q * (1.0f / C) + eps);
+    }
+  }
+  __syncthreads();
+  {
+    const float lw = lnw[c], lb = lnb[c];
+#pragma unroll
+    for (int p = 0; p < 49; ++p) {
+      const float mean = stats[2 * (tslot * 49 + p)], rstd = stats[2 * (tslot * 49 + p) + 1];
+      sOut[(tslot * 49 + p) * C + c] = (unsigned short)bits16<T>((acc[p] - mean) * rstd * lw + lb);
+    }
+  }
+  __syncthreads();
+  {
+    int q1 = tid / CP;                                 // slot*49 + p
+    int oslot = 0, orow = q1 / 7, ocol = q1 - orow * 7;   // q1 < 24 < 49 at start
+#pragma unroll 1
+    for (; q1 < NP; q1 += STEP) {
+      const int sl = (TILES == 2) ? oslot : 0;
+      const int oy = s_y0[sl] + 3 + orow, ox = s_x0[sl] + 3 + ocol;
+      if (s_ok[sl] && oy < H && ox < W)
+        *(u32x4*)(y + ((s_img[sl] + (int64_t)oy * W + ox) * C + pc8)) = *(const u32x4*)(sOut + q1 * C + pc8);
+      ocol += STEP % 7;
+      orow += STEP / 7;
+      if (ocol >= 7) { ocol -= 7; orow += 1; }
+      if (TILES == 2 && oslot == 0 && orow >= 7) { orow -= 7; oslot = 1; }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ K6: LN2d + space-to-depth
 // x (nimg,H,W,C) -> out (nimg,H/2,W/2,4C), K index (dy*2+dx)*C + c; floor(H/2): an odd last
 // row/col is dropped exactly as Conv2d(k=2,s=2) drops it (7 -> 3 in the 112-px pass).

@@ -1,5 +1,7 @@
 // Launch wrappers for kernels.h (included by kern_{f32,f16,bf16}.hip).
 #pragma once
+#include <cstdlib>
+
 #include "kernels.h"
 #include "kernels_dev.h"
 
@@ -36,10 +38,43 @@ static int launch_dw_c(const T* x, const float* wdw, const float* bdw, const flo
   return 0;
 }
 
+template <typename T, int C, bool DOT2>
+static int launch_dw_v2(const T* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb, T* y,
+                        int nimg, int H, int W, float eps, hipStream_t s) {
+  constexpr int TILES = 192 / C;
+  constexpr int LDS = TILES * 169 * C * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GCV_CHECK_HIP(hipFuncSetAttribute((const void*)dwconv7_ln_v2_kernel<T, C, DOT2>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  const int tiles = nimg * cdiv(H, 7) * cdiv(W, 7);
+  hipLaunchKernelGGL((dwconv7_ln_v2_kernel<T, C, DOT2>), dim3(cdiv(tiles, TILES)), dim3(192), LDS, s, x, wdw, bdw, lnw,
+                     lnb, y, nimg, H, W, eps);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// 0: v2 + dot2 (default for 16-bit C<=192), 1: v2 with fp32 FMA taps, 2: v1 everywhere   (env GCV_DWCONV_MODE)
+static inline int dwconv_mode() {
+  static const int mode = [] { const char* e = std::getenv("GCV_DWCONV_MODE"); return e ? std::atoi(e) : 0; }();
+  return mode;
+}
+
 template <typename T>
 int launch_dwconv7_ln(const T* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb, T* y,
                       int nimg, int H, int W, int C, float eps, hipStream_t s) {
   GCV_REQUIRE(nimg > 0 && H > 0 && W > 0, "dwconv: empty");
+  if constexpr (sizeof(T) == 2) {
+    const int mode = dwconv_mode();
+    if (mode != 2 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0) {
+      if (C == 96) return mode == 0 ? launch_dw_v2<T, 96, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s)
+                                    : launch_dw_v2<T, 96, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
+      if (C == 192) return mode == 0 ? launch_dw_v2<T, 192, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s)
+                                     : launch_dw_v2<T, 192, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
+    }
+  }
   switch (C) {
     case 96:  return launch_dw_c<T, 96>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
     case 192: return launch_dw_c<T, 192>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
