@@ -139,12 +139,21 @@ __global__ void __launch_bounds__(NW * 64) fused_mlp_kernel(const MlpArgs a) {
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[j][r] = 0.0f;
+    // W fragments are read one k-step ahead of the MFMAs that consume them (explicit register double
+    // buffer): hipcc otherwise emits ds_read -> s_waitcnt -> v_mfma chains that expose the LDS latency
+    {
+      u32x4 wf[2][NJ];
 #pragma unroll
-    for (int p = 0; p < KP1; ++p) {
+      for (int j = 0; j < NJ; ++j) wf[0][j] = *(const u32x4*)(s1 + (32 * j + lr) * ROW1 + lh * 16);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const u32x4 w = *(const u32x4*)(s1 + (32 * j + lr) * ROW1 + (2 * p + lh) * 16);
-        Mfma<T>::run(w, xf[p], acc1[j]);
+      for (int p = 0; p < KP1; ++p) {
+        if (p + 1 < KP1) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            wf[(p + 1) & 1][j] = *(const u32x4*)(s1 + (32 * j + lr) * ROW1 + (2 * (p + 1) + lh) * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) Mfma<T>::run(wf[p & 1][j], xf[p], acc1[j]);
       }
     }
     if (SPLIT && ch + 1 < NCH) {
@@ -166,12 +175,19 @@ __global__ void __launch_bounds__(NW * 64) fused_mlp_kernel(const MlpArgs a) {
         hf[q >> 1][2 * (q & 1)] = pk.x;
         hf[q >> 1][2 * (q & 1) + 1] = pk.y;
       }
+      {
+        u32x4 w2f[2][NO];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+        for (int o = 0; o < NO; ++o) w2f[0][o] = *(const u32x4*)(s2 + (32 * o + lr) * ROW2 + (2 * (2 * j) + lh) * 16);
 #pragma unroll
-        for (int o = 0; o < NO; ++o) {
-          const u32x4 w = *(const u32x4*)(s2 + (32 * o + lr) * ROW2 + (2 * (2 * j + s) + lh) * 16);
-          Mfma<T>::run(w, hf[s], acc2[o]);
+        for (int s = 0; s < 2; ++s) {
+          if (s == 0) {
+#pragma unroll
+            for (int o = 0; o < NO; ++o)
+              w2f[1][o] = *(const u32x4*)(s2 + (32 * o + lr) * ROW2 + (2 * (2 * j + 1) + lh) * 16);
+          }
+#pragma unroll
+          for (int o = 0; o < NO; ++o) Mfma<T>::run(w2f[s][o], hf[s], acc2[o]);
         }
       }
     }

@@ -254,26 +254,31 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
     if (kt + 1 < nkt) fetch(kt + 1);
     const unsigned char* sA = smem + (kt & 1) * (A_BYTES + B_BYTES);
     const unsigned char* sB = sA + A_BYTES;
-#pragma unroll
-    for (int t = 0; t < CPR / 2; ++t) {
-      u32x4 af[MI], bf[NI];
+    // fragments of chunk pair t+1 are read while the MFMAs of pair t run (register double buffer)
+    u32x4 af[2][MI], bf[2][NI];
+    auto read_frags = [&](int t, int slot) {
       const int c = 2 * t + lh;
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int row = wm0 + i * 32 + lr;
-        af[i] = *(const u32x4*)(sA + row * BKB + ((c ^ ((row >> SW_SHIFT) & (CPR - 1))) << 4));
+        af[slot][i] = *(const u32x4*)(sA + row * BKB + ((c ^ ((row >> SW_SHIFT) & (CPR - 1))) << 4));
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int row = wn0 + j * 32 + lr;
-        bf[j] = *(const u32x4*)(sB + row * BKB + ((c ^ ((row >> SW_SHIFT) & (CPR - 1))) << 4));
+        bf[slot][j] = *(const u32x4*)(sB + row * BKB + ((c ^ ((row >> SW_SHIFT) & (CPR - 1))) << 4));
       }
+    };
+    read_frags(0, 0);
+#pragma unroll
+    for (int t = 0; t < CPR / 2; ++t) {
+      if (t + 1 < CPR / 2) read_frags(t + 1, (t + 1) & 1);
       // Wt fragment is the MFMA "A" operand: the accumulator then has the TOKEN on the lane and 4
       // consecutive output channels in 4 consecutive registers (D row = channel, D col = token).
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j) Mfma<T>::run(bf[j], af[i], acc[i][j]);
+        for (int j = 0; j < NI; ++j) Mfma<T>::run(bf[t & 1][j], af[t & 1][i], acc[i][j]);
     }
     if (kt + 1 < nkt) stage((kt + 1) & 1);
     __syncthreads();
