@@ -1,0 +1,181 @@
+// Pipelined MFMA GEMM for the large pointwise layers (16-bit storage, plain A operand):
+//     C[m][n] = epilogue( sum_k A[m][k] * Wt[n][k] ),   N % 192 == 0, K % 32 == 0
+//
+// Why a second GEMM kernel: the register-staged kernel in gemm.h keeps ONE K tile per workgroup in
+// flight; at the ConvNeXt stage-2/3 shapes a K tile is ~400 MFMA cycles of work but ~1.8 us of
+// memory latency (the 4C-wide hidden operand streams from HBM), and its 128x96 tile moves 0.018 B of
+// operand per FLOP through L2.  This kernel
+//   * loads operands with LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write) into a ring
+//     of S = 4 K-tile stages and waits with a COUNTED vmcnt, so three stages (60 KB per workgroup,
+//     120 KB per CU) are in flight while one is consumed — one raw s_barrier per K tile
+//   * uses a 128 x 192 tile, 4 waves as 2(M) x 2(N), 64 x 96 per wave (2x3 32x32 accumulators):
+//     0.013 B/FLOP from L2 and 0.83 LDS fragment reads per MFMA
+//   * LDS image is lane-linear per DMA instruction (16 rows x 64 B); the bank swizzle is applied to the
+//     SOURCE chunk each lane fetches and to the fragment read (guide §5.4 rule 21)
+// Out-of-range rows are clamped to the last valid row when loading (their results are never stored);
+// K has no tail by construction.  Epilogue as in gemm.h (tokens on lanes, LDS-staged coalesced
+// stores); the layer-scale residual is added in registers before staging so the stage stays 16-bit.
+#pragma once
+#include "gemm.h"
+
+namespace gcv {
+
+constexpr int kGldsBM = 128, kGldsBN = 192, kGldsBKB = 64, kGldsStages = 4;
+
+template <typename T> struct GldsSmem {
+  static constexpr int kStage = (kGldsBM + kGldsBN) * kGldsBKB;            // 20480
+  static constexpr int kMain = kGldsStages * kStage;                       // 81920
+  static constexpr int kEpi = kGldsBM * (kGldsBN / 2 + 2) * 4;             // 16-bit staging
+  static constexpr int bytes = kMain > kEpi ? kMain : kEpi;
+};
+
+template <typename T, int EPI, int ACT>
+__global__ void __launch_bounds__(256, 2) gemm_glds_kernel(const GemmArgs g) {
+  static_assert(sizeof(T) == 2, "LDS-DMA GEMM is built for 16-bit storage");
+  static_assert(EPI == EPI_BIAS_ACT || EPI == EPI_RESID, "epilogues: bias+act, layer-scale residual");
+  constexpr int BM = kGldsBM, BN = kGldsBN, BKB = kGldsBKB, S = kGldsStages;
+  constexpr int EPC = 8, CPR = BKB / 16, BK = CPR * EPC;          // 4 chunks, 32 k per tile
+  constexpr int STAGE = GldsSmem<T>::kStage;
+  constexpr int A_BYTES = BM * BKB;
+  constexpr int NQ = STAGE / 1024;                                // DMA wave-instructions per stage (20)
+  constexpr int QPW = NQ / 4;                                     // per wave (5)
+  constexpr int MI = 2, NI = 3;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 96;
+
+  const int ntn = g.N / BN;
+  const int ntm = (g.M + BM - 1) / BM;
+  const int bid = xcd_remap(blockIdx.x, ntm * ntn);
+  const int m0 = (bid / ntn) * BM;
+  const int n0 = (bid % ntn) * BN;
+  const int nkt = g.K / BK;
+
+  // ---- per-lane DMA sources: instruction q = wave + 4 i covers LDS rows [16 q, 16 q + 16) of the stage
+  const T* src[QPW];
+#pragma unroll
+  for (int i = 0; i < QPW; ++i) {
+    const int q = wave + 4 * i;
+    const int rl = q * 16 + (lane >> 2);                 // row inside the stage image
+    const int phys = lane & 3;
+    if (rl < BM) {
+      const int c = phys ^ ((rl >> 2) & 3);
+      const int m = min(m0 + rl, g.M - 1);
+      src[i] = (const T*)g.A + (int64_t)m * g.lda + c * EPC;
+    } else {
+      const int rb = rl - BM;
+      const int c = phys ^ ((rb >> 2) & 3);
+      const int n = min(n0 + rb, g.N - 1);
+      src[i] = (const T*)g.Wt + (int64_t)n * g.K + c * EPC;
+    }
+  }
+  auto issue = [&](int kt) {
+    unsigned char* base = smem + (kt % S) * STAGE;
+#pragma unroll
+    for (int i = 0; i < QPW; ++i) {
+      const int q = wave + 4 * i;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)kt * BK),
+                                       (__attribute__((address_space(3))) void*)(base + q * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  auto compute = [&](int kt) {
+    const unsigned char* sA = smem + (kt % S) * STAGE;
+    const unsigned char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int t = 0; t < CPR / 2; ++t) {
+      const int c = 2 * t + lh;
+      u32x4 af[MI], bf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = wm0 + i * 32 + lr;
+        af[i] = *(const u32x4*)(sA + row * BKB + ((c ^ ((row >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int row = wn0 + j * 32 + lr;
+        bf[j] = *(const u32x4*)(sB + row * BKB + ((c ^ ((row >> 2) & 3)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) Mfma<T>::run(bf[j], af[i], acc[i][j]);
+    }
+  };
+
+  // ---- pipeline: stages kt+1 .. kt+S-2 stay in flight while stage kt is consumed ----
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s)
+    if (s < nkt) issue(s);
+  const int n_steady = nkt - (S - 2) > 0 ? nkt - (S - 2) : 0;
+  for (int kt = 0; kt < n_steady; ++kt) {
+    // my DMAs for stage kt have landed once at most (S-2) younger stages (QPW each) are outstanding
+    // (one asm statement so no LDS access can be scheduled between the wait and the barrier)
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((S - 2) * QPW) : "memory");   // stage kt landed everywhere; all left kt-1
+    if (kt + S - 1 < nkt) issue(kt + S - 1); // refill the buffer stage kt-1 used
+    compute(kt);
+  }
+  for (int kt = n_steady; kt < nkt; ++kt) {  // drain: fewer stages outstanding, wait for all of them
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    compute(kt);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all waves done reading the ring before it is reused
+
+  // ---- epilogue: token on the lane, 4 consecutive channels in 4 consecutive registers ----
+  constexpr int SROW = BN / 2 + 2;           // dwords per staged row (16-bit), 2*odd -> conflict-free b64 writes
+  typedef T t4 __attribute__((ext_vector_type(4)));
+  uint32_t* sC = reinterpret_cast<uint32_t*>(smem);
+  T* Cp = (T*)g.C;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int ml = wm0 + i * 32 + lr;
+    const int m = m0 + ml;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nl = wn0 + j * 32 + 8 * q + 4 * lh;
+        const int n = n0 + nl;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) bv = *(const f32x4*)(g.bias + n);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_fn<ACT>(acc[i][j][4 * q + e] + bv[e]);
+        if (EPI == EPI_RESID) {
+          const f32x4 gv = *(const f32x4*)(g.gamma + n);
+          const int64_t mm = m < g.M ? m : g.M - 1;
+          const t4 r = *(const t4*)((const T*)g.resid + mm * g.ldc + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], gv[e], to_f(r[e]));
+        }
+        t4 o = {from_f<T>(v[0]), from_f<T>(v[1]), from_f<T>(v[2]), from_f<T>(v[3])};
+        *(t4*)(sC + ml * SROW + (nl >> 1)) = o;
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int PPR = BN / 4;
+  for (int idx = tid; idx < BM * PPR; idx += 256) {
+    const int rl = idx / PPR, pc = idx - rl * PPR;
+    const int m = m0 + rl;
+    if (m < g.M) *(t4*)(Cp + (int64_t)m * g.ldc + n0 + 4 * pc) = *(const t4*)(sC + rl * SROW + 2 * pc);
+  }
+}
+
+template <typename T> int launch_gemm_glds(const GemmArgs& g, int epi, hipStream_t s);
+// true when (g, a_mode, epi) is a shape the LDS-DMA kernel covers
+template <typename T> bool gemm_glds_applicable(const GemmArgs& g, int a_mode, int epi);
+
+}  // namespace gcv

@@ -1,6 +1,7 @@
 // Tile-config selection + launch for gemm_kernel (included by gemm_{f32,f16,bf16}.hip).
 #pragma once
 #include "gemm.h"
+#include "gemm_glds_impl.h"
 
 namespace gcv {
 
@@ -61,6 +62,9 @@ template <typename T> int launch_gemm(const GemmArgs& g, int a_mode, int epi, hi
   if (epi == EPI_RESID) GCV_REQUIRE(g.gamma && g.resid && aligned16(g.gamma), "EPI_RESID needs gamma and resid");
   if (epi == EPI_POOL4) GCV_REQUIRE(g.M % 4 == 0, "EPI_POOL4 needs M % 4 == 0");
   if (epi == EPI_CONVT) GCV_REQUIRE(g.N == 4 << g.cout_log2 && g.cout_log2 >= 2 && g.M % (g.H * g.W) == 0, "EPI_CONVT shape");
+  if constexpr (sizeof(T) == 2) {
+    if (gemm_glds_applicable<T>(g, a_mode, epi)) return launch_gemm_glds<T>(g, epi, s);
+  }
   // 16-bit GEMMs whose K leaves a tail of <= 32 use 64-byte LDS rows (K tile 32) instead of padding a 64-k tile
   const bool short_k = sizeof(T) == 2 && (g.K % 64) != 0 && (g.K % 64) <= 32;
 

@@ -409,3 +409,35 @@ def test_fused_mlp_layerscale_residual(dt, C, M):
     kutil.call("gcv_k_fused_mlp", _lib.dtype_code(dtype), C, ptr(D(x, dtype)), ptr(D(w1, dtype)), ptr(D(b1)),
                ptr(D(w2)), ptr(D(b2)), ptr(D(gamma)), ptr(out), ptr(out), M)
     assert_close(out, want, tol(dtype, 2.0), "fused mlp")
+
+
+# ----------------------------------------------------------------------------- LDS-DMA pipelined GEMM
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K,act", [
+    (700, 1536, 384, 2),     # ConvNeXt stage-2 pw1 class (GELU)
+    (513, 192, 32, 0),       # one K tile  (pipeline shorter than the ring)
+    (256, 192, 64, 0),       # two K tiles
+    (300, 384, 96, 2),       # three K tiles, M tail
+    (384, 768, 128, 0),      # exactly ring depth
+    (1000, 384, 3072, 0),    # long K
+])
+def test_gemm_lds_dma_pipeline_bias_act(dt, M, N, K, act):
+    dtype = DTYPES[dt]
+    A, W = q(rnd((M, K), 1), dtype), q(rnd((N, K), 2, 1 / math.sqrt(K)), dtype)
+    bias = rnd((N,), 3, 0.1)
+    C = torch.full((M, N), 7.0, dtype=dtype, device=dev())
+    gemm(dtype, _lib.A_PLAIN, _lib.EPI_BIAS_ACT, D(A, dtype), D(W, dtype), C, M, N, K, lda=K, ldc=N, bias=D(bias), act=act)
+    assert_close(C, act_ref(A @ W.t() + bias, act), tol(dtype, 2.0), "glds gemm")
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K", [(1000, 384, 1536), (257, 768, 3072), (640, 192, 768)])
+def test_gemm_lds_dma_pipeline_residual(dt, M, N, K):
+    dtype = DTYPES[dt]
+    A, W = q(rnd((M, K), 1), dtype), q(rnd((N, K), 2, 1 / math.sqrt(K)), dtype)
+    bias, gamma = rnd((N,), 3, 0.1), rnd((N,), 4, 0.5)
+    X = q(rnd((M, N), 5), dtype)
+    Xd = D(X, dtype).clone()
+    gemm(dtype, _lib.A_PLAIN, _lib.EPI_RESID, D(A, dtype), D(W, dtype), Xd, M, N, K, lda=K, ldc=N, bias=D(bias),
+         gamma=D(gamma), resid=Xd)
+    assert_close(Xd, X + gamma * (A @ W.t() + bias), tol(dtype, 2.0), "glds gemm resid")
