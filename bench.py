@@ -206,10 +206,12 @@ def main():
         for h in handles:
             h.profile_enable(False)
         total_ms = sum(v["ms"] for v in agg.values())
-        # kernel families: the two pointwise GEMMs are the same kernel template (gemm_kernel, plain A)
+        # kernel families: every pointwise-MLP contraction of the ConvNeXt blocks runs on the MFMA GEMM
+        # templates (gemm_glds_kernel / gemm_kernel with plain A, and the fused two-GEMM MLP kernel)
+        MFMA_TAGS = ("cnx.pw1_gelu", "cnx.pw2_scale_res", "cnx.fused_mlp")
         fam = {}
         for tag, v in agg.items():
-            f = "mfma_gemm(cnx.pw1_gelu+cnx.pw2_scale_res)" if tag in ("cnx.pw1_gelu", "cnx.pw2_scale_res") else tag
+            f = "mfma_gemm(cnx.pw1_gelu+cnx.pw2_scale_res+cnx.fused_mlp)" if tag in MFMA_TAGS else tag
             g = fam.setdefault(f, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             for k in g:
                 g[k] += v[k]

@@ -18,7 +18,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgenconvit_hip.so")
+LIB_PATH = os.environ.get("GCV_LIB_PATH") or os.path.join(_HERE, "lib", "libgenconvit_hip.so")   # override: diagnostic builds
 
 GCV_F32, GCV_BF16, GCV_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_LEAKY = 0, 1, 2, 3

@@ -101,7 +101,7 @@ dwconv7_ln_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*[49][
   const int c = tid - tslot * C;
   const int tiles_x = (W + 6) / 7, tiles_y = (H + 6) / 7;
   const int total = nimg * tiles_x * tiles_y;
-  const int tile_raw = blockIdx.x * TILES + tslot;
+  const int tile_raw = xcd_remap(blockIdx.x, gridDim.x) * TILES + tslot;   // contiguous tile runs per XCD
   const bool tile_ok = tile_raw < total;
   const int tile = tile_ok ? tile_raw : total - 1;   // idle slot recomputes the last tile, stores nothing
   const int tx = tile % tiles_x, t2 = tile / tiles_x;
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(192) dwconv7_ln_v2_kernel(const T* __restrict_
   const int tid = threadIdx.x;
   const int tiles_x = (W + 6) / 7, tiles_y = (H + 6) / 7;
   const int total = nimg * tiles_x * tiles_y;
-  const int tile0 = blockIdx.x * TILES;
+  const int tile0 = xcd_remap(blockIdx.x, gridDim.x) * TILES;   // contiguous tile runs per XCD (halo reuse in L2)
 
   // ---- 1. stage the halo windows -----------------------------------------------------------
   // batches of independent loads first, LDS stores after: a load->store loop would expose the full
@@ -435,6 +435,203 @@ __global__ void __launch_bounds__(192) dwconv7_ln_v2_kernel(const T* __restrict_
       if (ocol >= 7) { ocol -= 7; orow += 1; }
       if (TILES == 2 && oslot == 0 && orow >= 7) { orow -= 7; oslot = 1; }
     }
+  }
+}
+
+// ------------------------------------------------------------------ K4 v3 (16-bit, C = 96 / 192)
+// Occupancy-first decomposition of the same op: one workgroup = one 7x7 tile, one THREAD = one channel
+// of RPT output rows (7 x RPT accumulators), i.e. 672 (C=96) / 768 (C=192) threads per tile instead of
+// 96 / 192.  The per-tile costs (halo staging, LayerNorm statistics, coalesced store) are spread over
+// 7x / 4x more threads, a thread needs ~60 VGPRs, and the CU holds ~32 waves, so the LDS / memory
+// waits of one wave are covered by the others (v2: 6 waves per CU, 43 % of wave time in s_waitcnt).
+// Taps live in LDS as packed pairs [28][C]; inputs in LDS [13x13][C]; MACs by v_dot2c (fp32 accumulate).
+template <typename T, int C, int RPT, bool DOT2>
+__global__ void __launch_bounds__(((7 + RPT - 1) / RPT) * C)
+dwconv7_ln_v3_kernel(const T* __restrict__ x, const float* __restrict__ wdw, const float* __restrict__ bdw,
+                     const float* __restrict__ lnw, const float* __restrict__ lnb, T* __restrict__ y, int nimg, int H,
+                     int W, float eps) {
+  static_assert(sizeof(T) == 2 && (C == 96 || C == 192), "v3 covers 16-bit storage, C = 96 / 192");
+  constexpr int NRG = (7 + RPT - 1) / RPT;            // row groups (threads per channel)
+  constexpr int NT = NRG * C;
+  constexpr int CP = C / 8;                           // 16-byte pieces per pixel
+  constexpr int IN_BYTES = 169 * C * 2;
+  constexpr int STAT_OFF = 49 * C * 4;
+  constexpr int OUT_OFF = (STAT_OFF + 49 * 8 + 255) & ~255;
+  static_assert(OUT_OFF + 49 * C * 2 <= IN_BYTES, "LN / output staging must fit in the halo window");
+  extern __shared__ __attribute__((aligned(16))) unsigned char dw3_lds[];
+  unsigned short* sIn = reinterpret_cast<unsigned short*>(dw3_lds);
+  float* sval = reinterpret_cast<float*>(dw3_lds);
+  float* stats = reinterpret_cast<float*>(dw3_lds + STAT_OFF);
+  unsigned short* sOut = reinterpret_cast<unsigned short*>(dw3_lds + OUT_OFF);
+  constexpr bool W_IN_LDS = (C == 96);                 // C=192: taps straight from global so two tiles fit a CU
+  uint32_t* sW2 = reinterpret_cast<uint32_t*>(dw3_lds + IN_BYTES);     // [28][C] packed tap pairs
+
+  const int tid = threadIdx.x;
+  const int tiles_x = (W + 6) / 7, tiles_y = (H + 6) / 7;
+  // XCD-aware order: blocks are dealt round-robin over the 8 XCDs, so give every XCD a contiguous run of
+  // tiles (whole images): neighbouring tiles then find their shared halo in that XCD's L2 instead of
+  // re-fetching it through the fabric (the 13x13 window is 3.45x the 7x7 core)
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = tile % tiles_x, t2 = tile / tiles_x;
+  const int ty = t2 % tiles_y, b = t2 / tiles_y;
+  const int x0 = tx * 7, y0 = ty * 7;
+  const int64_t img = (int64_t)b * H * W;
+
+  // ---- taps -> LDS as (tap(ky,2j), tap(ky,2j+1)) pairs, tap(ky,7) = 0 ----
+  for (int i = tid; W_IN_LDS && i < 28 * C; i += NT) {
+    const int c = i % C, kj = i / C;
+    const int ky = kj >> 2, j = kj & 3;
+    const uint32_t lo = bits16<T>(wdw[(ky * 7 + 2 * j) * C + c]);
+    const uint32_t hi = (j < 3) ? bits16<T>(wdw[(ky * 7 + 2 * j + 1) * C + c]) : 0u;
+    sW2[i] = lo | (hi << 16);
+  }
+  // ---- halo window -> LDS (independent 16-byte loads, zero outside the image) ----
+  constexpr int NPIECE = 169 * CP;
+  constexpr int NIT = (NPIECE + NT - 1) / NT;
+  {
+    u32x4 v[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int idx = tid + i * NT;
+      const int pix = idx / CP, pc = idx - pix * CP;
+      const int r = pix / 13, sx = pix - r * 13;
+      const int iy = y0 + r - 3, ix = x0 + sx - 3;
+      const bool ok = idx < NPIECE && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const int64_t off = ok ? ((img + (int64_t)iy * W + ix) * C + 8 * pc) : 0;
+      const u32x4 t = *(const u32x4*)(x + off);
+      const uint32_t m = ok ? 0xffffffffu : 0u;
+      v[i] = u32x4{t[0] & m, t[1] & m, t[2] & m, t[3] & m};
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int idx = tid + i * NT;
+      if (idx < NPIECE) *(u32x4*)(sIn + idx * 8) = v[i];
+    }
+  }
+  __syncthreads();
+
+  // ---- 7x7 taps: thread = (row group rg, channel c) ----
+  const int rg = tid / C, c = tid - rg * C;
+  const int oy0 = rg * RPT;
+  float acc[RPT][7];
+  const float bv = bdw[c];
+#pragma unroll
+  for (int rr = 0; rr < RPT; ++rr)
+#pragma unroll
+    for (int ox = 0; ox < 7; ++ox) acc[rr][ox] = bv;
+#ifndef GCV_DW_ABLATE
+#define GCV_DW_ABLATE 0
+#endif
+  if (DOT2) {
+    uint32_t w2[28];
+#pragma unroll
+    for (int k = 0; k < 28; ++k) {
+      if (W_IN_LDS) {
+        w2[k] = sW2[k * C + c];
+      } else {
+        const int ky = k >> 2, j = k & 3;
+        const uint32_t lo = bits16<T>(wdw[(ky * 7 + 2 * j) * C + c]);
+        const uint32_t hi = (j < 3) ? bits16<T>(wdw[(ky * 7 + 2 * j + 1) * C + c]) : 0u;
+        w2[k] = lo | (hi << 16);
+      }
+    }
+#pragma unroll
+    for (int ri = 0; ri < ((GCV_DW_ABLATE & 1) ? 1 : 6 + RPT); ++ri) {   // input rows oy0 .. oy0 + 6 + RPT - 1
+      const int r = min(oy0 + ri, 12);                 // (clamped rows only feed row slots that are never stored)
+      uint32_t raw[14];
+#pragma unroll
+      for (int s = 0; s < 13; ++s) raw[s] = sIn[(r * 13 + s) * C + c];
+      raw[13] = 0u;
+      uint32_t pp[13];
+#pragma unroll
+      for (int s = 0; s < 13; ++s) pp[s] = raw[s] | (raw[s + 1] << 16);
+#pragma unroll
+      for (int rr = 0; rr < RPT; ++rr) {
+        const int ky = ri - rr;                        // compile-time after unrolling
+        if (ky >= 0 && ky < 7) {
+#pragma unroll
+          for (int ox = 0; ox < 7; ++ox)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[rr][ox] = Dot2<T>::run(pp[ox + 2 * j], w2[ky * 4 + j], acc[rr][ox]);
+        }
+      }
+    }
+  } else {
+    // plain fp32 FMAs (taps exact fp32): at 8 waves per SIMD v_fma_f32 issues every 2 cycles (64 MACs),
+    // which beats v_dot2c_f32_f16 (128 MACs per ~8-10 cycles measured here)
+    float w[49];
+#pragma unroll
+    for (int k = 0; k < 49; ++k) w[k] = wdw[k * C + c];
+#pragma unroll
+    for (int ri = 0; ri < ((GCV_DW_ABLATE & 1) ? 1 : 6 + RPT); ++ri) {
+      const int r = min(oy0 + ri, 12);
+      float v[13];
+#pragma unroll
+      for (int s = 0; s < 13; ++s) v[s] = from_bits16<T>(sIn[(r * 13 + s) * C + c]);
+#pragma unroll
+      for (int rr = 0; rr < RPT; ++rr) {
+        const int ky = ri - rr;
+        if (ky >= 0 && ky < 7) {
+#pragma unroll
+          for (int ox = 0; ox < 7; ++ox)
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) acc[rr][ox] = fmaf(v[ox + kx], w[ky * 7 + kx], acc[rr][ox]);
+        }
+      }
+    }
+  }
+  __syncthreads();                                     // halo window is free: reuse it for LayerNorm
+
+#pragma unroll
+  for (int rr = 0; rr < RPT; ++rr) {
+    const int oy = oy0 + rr;
+    if (oy < 7) {
+#pragma unroll
+      for (int ox = 0; ox < 7; ++ox) sval[(oy * 7 + ox) * C + c] = acc[rr][ox];
+    }
+  }
+  __syncthreads();
+  {
+    const int grp = tid >> 5, gl = tid & 31;
+    for (int p = grp; p < ((GCV_DW_ABLATE & 2) ? 0 : 49); p += NT / 32) {
+      const float* row = sval + p * C;
+      float s = 0.0f;
+#pragma unroll
+      for (int k = 0; k < C / 32; ++k) s += row[gl + 32 * k];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      const float mean = s * (1.0f / C);
+      float q = 0.0f;
+#pragma unroll
+      for (int k = 0; k < C / 32; ++k) { const float d = row[gl + 32 * k] - mean; q = fmaf(d, d, q); }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+      if (gl == 0) {
+        stats[2 * p] = mean;
+        stats[2 * p + 1] = 1.0f / sqrtf(q * (1.0f / C) + eps);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const float lw = lnw[c], lb = lnb[c];
+#pragma unroll
+    for (int rr = 0; rr < RPT; ++rr) {
+      const int oy = oy0 + rr;
+      if (oy < 7) {
+#pragma unroll
+        for (int ox = 0; ox < 7; ++ox) {
+          const int p = oy * 7 + ox;
+          sOut[p * C + c] = (unsigned short)bits16<T>((acc[rr][ox] - stats[2 * p]) * stats[2 * p + 1] * lw + lb);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 49 * CP; idx += NT) {
+    const int p = idx / CP, pc = idx - p * CP;
+    const int oy = y0 + p / 7, ox = x0 + p % 7;
+    if (oy < H && ox < W) *(u32x4*)(y + ((img + (int64_t)oy * W + ox) * C + 8 * pc)) = *(const u32x4*)(sOut + p * C + 8 * pc);
   }
 }
 

@@ -56,7 +56,27 @@ static int launch_dw_v2(const T* x, const float* wdw, const float* bdw, const fl
   return 0;
 }
 
-// 0: v2 + dot2 (default for 16-bit C<=192), 1: v2 with fp32 FMA taps, 2: v1 everywhere   (env GCV_DWCONV_MODE)
+template <typename T, int C, int RPT, bool DOT2>
+static int launch_dw_v3(const T* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb, T* y,
+                        int nimg, int H, int W, float eps, hipStream_t s) {
+  constexpr int NT = ((7 + RPT - 1) / RPT) * C;
+  constexpr int LDS = 169 * C * 2 + (C == 96 ? 28 * C * 4 : 0);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (LDS > 64 * 1024)
+      GCV_CHECK_HIP(hipFuncSetAttribute((const void*)dwconv7_ln_v3_kernel<T, C, RPT, DOT2>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  const int tiles = nimg * cdiv(H, 7) * cdiv(W, 7);
+  hipLaunchKernelGGL((dwconv7_ln_v3_kernel<T, C, RPT, DOT2>), dim3(tiles), dim3(NT), LDS, s, x, wdw, bdw, lnw, lnb, y, nimg, H,
+                     W, eps);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// 0: v3 + dot2 (default for 16-bit C<=192), 4: v3 with fp32 FMA taps, 1: v2 + dot2, 2: v1 everywhere,
+// 3: v2 with fp32 FMA taps (env GCV_DWCONV_MODE, A/B switch for profiling)
 static inline int dwconv_mode() {
   static const int mode = [] { const char* e = std::getenv("GCV_DWCONV_MODE"); return e ? std::atoi(e) : 0; }();
   return mode;
@@ -69,10 +89,18 @@ int launch_dwconv7_ln(const T* x, const float* wdw, const float* bdw, const floa
   if constexpr (sizeof(T) == 2) {
     const int mode = dwconv_mode();
     if (mode != 2 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0) {
-      if (C == 96) return mode == 0 ? launch_dw_v2<T, 96, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s)
-                                    : launch_dw_v2<T, 96, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
-      if (C == 192) return mode == 0 ? launch_dw_v2<T, 192, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s)
-                                     : launch_dw_v2<T, 192, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
+      if (C == 96) {
+        if (mode == 0) return launch_dw_v3<T, 96, 1, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
+        if (mode == 4) return launch_dw_v3<T, 96, 1, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
+        return mode == 1 ? launch_dw_v2<T, 96, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s)
+                         : launch_dw_v2<T, 96, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
+      }
+      if (C == 192) {
+        if (mode == 0) return launch_dw_v3<T, 192, 2, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
+        if (mode == 4) return launch_dw_v3<T, 192, 2, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
+        return mode == 1 ? launch_dw_v2<T, 192, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s)
+                         : launch_dw_v2<T, 192, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
+      }
     }
   }
   switch (C) {
