@@ -118,6 +118,19 @@ int launch_ln_patchify(const T* x, const float* w, const float* b, T* out, int n
                        hipStream_t s) {
   GCV_REQUIRE(C <= 768 && nimg > 0, "ln_patchify: C <= 768");
   const int64_t total = (int64_t)nimg * H * W;
+  if constexpr (sizeof(T) == 2) {
+    const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 3u) == 0;
+#define GCV_LNP(CC)                                                                                              \
+    if (C == CC && al) {                                                                                         \
+      constexpr int PPB = 256 / (CC / 6);                                                                        \
+      hipLaunchKernelGGL((ln_patchify_vec_kernel<T, CC>), dim3((unsigned)cdiv64(total, PPB)), dim3(256), 0, s, x, w, b, \
+                         out, nimg, H, W, eps);                                                                  \
+      GCV_CHECK_HIP(hipGetLastError());                                                                          \
+      return 0;                                                                                                  \
+    }
+    GCV_LNP(96) GCV_LNP(192) GCV_LNP(384)
+#undef GCV_LNP
+  }
   hipLaunchKernelGGL((ln_patchify_kernel<T>), dim3((unsigned)cdiv64(total, 4)), dim3(256), 0, s, x, w, b, out, nimg, H,
                      W, C, eps);
   GCV_CHECK_HIP(hipGetLastError());
