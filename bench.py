@@ -70,6 +70,23 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def measured_traffic(kernel_family: str):
+    """HBM bytes per launch of the family from the committed rocprofv3 PMC run of this same command
+    (profiles/r*_traffic.json, produced by profiles/pmc_bench_traffic.sh: FETCH_SIZE x2 + WRITE_SIZE in
+    separate passes).  PMC counters cannot be collected from inside the process, so this is the newest
+    committed measurement, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    fam = "mfma_gemm" if kernel_family.startswith("mfma_gemm") else ("dwconv7_ln" if "dwconv" in kernel_family else None)
+    try:
+        d = json.load(open(files[-1]))["families"][fam]
+        return round(d["hbm_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,8 +241,10 @@ def main():
         else:
             achieved = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
             peak, unit = PEAK["hbm"], "GB/s"
+        traffic, traffic_src = measured_traffic(name)
         roof = {"kernel": name, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-                "frac": round(achieved / peak, 4), "traffic": None,
+                "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
                 "launches_per_step": d["launches"] // max(a.profile_steps, 1), "avg_launch_ms": round(avg_ms, 4),
                 "share_of_step": round(d["ms"] / total_ms, 3),
                 "breakdown_ms_per_step": {k: round(v["ms"] / max(a.profile_steps, 1), 3)
