@@ -18,6 +18,10 @@
 #pragma once
 #include "gemm.h"
 
+#ifndef GCV_MLP_ABLATE
+#define GCV_MLP_ABLATE 0   // diagnostic builds only: 1 = no GELU, 2 = no weight streaming after chunk 0, 4 = no GEMM2
+#endif
+
 namespace gcv {
 
 struct MlpArgs {
@@ -45,7 +49,7 @@ template <typename T, int C, int NW> struct MlpSmem {
 };
 
 template <typename T, int C, int NW>
-__global__ void __launch_bounds__(NW * 64) fused_mlp_kernel(const MlpArgs a) {
+__global__ void __launch_bounds__(NW * 64, 2) fused_mlp_kernel(const MlpArgs a) {
   static_assert(sizeof(T) == 2, "fused MLP is built for 16-bit storage");
   static_assert(C == 96 || C == 192, "fused MLP covers the C=96 and C=192 stages");
   constexpr int HC = kMlpHC;
@@ -129,7 +133,7 @@ __global__ void __launch_bounds__(NW * 64) fused_mlp_kernel(const MlpArgs a) {
   __syncthreads();
 
   for (int ch = 0; ch < NCH; ++ch) {
-    if (ch + 1 < NCH) fetch(ch + 1, 0);
+    if (!(GCV_MLP_ABLATE & 2) && ch + 1 < NCH) fetch(ch + 1, 0);
     const unsigned char* s1 = smem + (ch & 1) * BUF;
     const unsigned char* s2 = s1 + HC * ROW1;
 
@@ -139,24 +143,30 @@ __global__ void __launch_bounds__(NW * 64) fused_mlp_kernel(const MlpArgs a) {
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[j][r] = 0.0f;
-    // W fragments are read one k-step ahead of the MFMAs that consume them (explicit register double
-    // buffer): hipcc otherwise emits ds_read -> s_waitcnt -> v_mfma chains that expose the LDS latency
+    // W1 fragments are read in batches of GB k-steps (GB*NJ ds_read_b128) and consumed by GB*NJ MFMAs;
+    // sched_barriers fence the batches.  Left to itself hipcc emits ds_read -> s_waitcnt -> v_mfma
+    // chains: at 2 waves per SIMD every one of the 144 MFMAs of a token tile then waits ~150 cycles
+    // for its own LDS read (10 us of a 26 us workgroup).
     {
-      u32x4 wf[2][NJ];
+      constexpr int GB = (C == 96) ? 3 : 2;
+      static_assert(KP1 % GB == 0, "k-steps per batch");
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) wf[0][j] = *(const u32x4*)(s1 + (32 * j + lr) * ROW1 + lh * 16);
+      for (int p0 = 0; p0 < KP1; p0 += GB) {
+        u32x4 wf[GB][NJ];
 #pragma unroll
-      for (int p = 0; p < KP1; ++p) {
-        if (p + 1 < KP1) {
+        for (int pp = 0; pp < GB; ++pp)
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
-            wf[(p + 1) & 1][j] = *(const u32x4*)(s1 + (32 * j + lr) * ROW1 + (2 * (p + 1) + lh) * 16);
-        }
+            wf[pp][j] = *(const u32x4*)(s1 + (32 * j + lr) * ROW1 + (2 * (p0 + pp) + lh) * 16);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) Mfma<T>::run(wf[p & 1][j], xf[p], acc1[j]);
+        for (int pp = 0; pp < GB; ++pp)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) Mfma<T>::run(wf[pp][j], xf[p0 + pp], acc1[j]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (SPLIT && ch + 1 < NCH) {
+    if (!(GCV_MLP_ABLATE & 2) && SPLIT && ch + 1 < NCH) {
       stash((ch + 1) & 1, 0);
       fetch(ch + 1, 1);
     }
@@ -170,28 +180,33 @@ __global__ void __launch_bounds__(NW * 64) fused_mlp_kernel(const MlpArgs a) {
         typedef T t4 __attribute__((ext_vector_type(4)));
         t4 h4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) h4[e] = from_f<T>(act_fn<ACT_GELU>(acc1[j][4 * q + e] + bv[e]));
+        for (int e = 0; e < 4; ++e)
+          h4[e] = from_f<T>((GCV_MLP_ABLATE & 1) ? (acc1[j][4 * q + e] + bv[e]) : act_fn<ACT_GELU>(acc1[j][4 * q + e] + bv[e]));
         const uint2 pk = __builtin_bit_cast(uint2, h4);
         hf[q >> 1][2 * (q & 1)] = pk.x;
         hf[q >> 1][2 * (q & 1) + 1] = pk.y;
       }
       {
-        u32x4 w2f[2][NO];
+        // SB k-steps of this 32-hidden group per batch: SB*NO fragment reads, then SB*NO MFMAs
+        constexpr int SB = (C == 96) ? 2 : 1;
 #pragma unroll
-        for (int o = 0; o < NO; ++o) w2f[0][o] = *(const u32x4*)(s2 + (32 * o + lr) * ROW2 + (2 * (2 * j) + lh) * 16);
+        for (int s0 = 0; s0 < 2; s0 += SB) {
+          u32x4 w2f[SB][NO];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          if (s == 0) {
+          for (int s = 0; s < SB; ++s)
 #pragma unroll
             for (int o = 0; o < NO; ++o)
-              w2f[1][o] = *(const u32x4*)(s2 + (32 * o + lr) * ROW2 + (2 * (2 * j + 1) + lh) * 16);
-          }
+              w2f[s][o] = *(const u32x4*)(s2 + (32 * o + lr) * ROW2 + (2 * (2 * j + s0 + s) + lh) * 16);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int o = 0; o < NO; ++o) Mfma<T>::run(w2f[s][o], hf[s], acc2[o]);
+          for (int s = 0; s < SB; ++s)
+#pragma unroll
+            for (int o = 0; o < ((GCV_MLP_ABLATE & 4) ? 1 : NO); ++o) Mfma<T>::run(w2f[s][o], hf[s0 + s], acc2[o]);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
-    if (ch + 1 < NCH) stash((ch + 1) & 1, SPLIT ? 1 : 0);
+    if (!(GCV_MLP_ABLATE & 2) && ch + 1 < NCH) stash((ch + 1) & 1, SPLIT ? 1 : 0);
     __syncthreads();
   }
 
