@@ -22,7 +22,25 @@
 #define GCV_MLP_ABLATE 0   // diagnostic builds only: 1 = no GELU, 2 = no weight streaming after chunk 0, 4 = no GEMM2
 #endif
 
+#ifndef GCV_MLP_STAMPS
+#define GCV_MLP_STAMPS 0   // diagnostic builds only: s_memtime stamps of workgroups 0..63 (wave 0) into a side buffer
+#endif
+
 namespace gcv {
+
+#if GCV_MLP_STAMPS
+__device__ unsigned long long gcv_mlp_stamps[64 * 16];
+#define GCV_STAMP(i)                                                                              \
+  do {                                                                                            \
+    if (blockIdx.x < 64 && threadIdx.x == 0) {                                                    \
+      unsigned long long _t;                                                                      \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                   \
+      gcv_mlp_stamps[blockIdx.x * 16 + (i)] = _t;                                                 \
+    }                                                                                             \
+  } while (0)
+#else
+#define GCV_STAMP(i) do { } while (0)
+#endif
 
 struct MlpArgs {
   const void* X;       // (M, C) LayerNorm'ed dw-conv output
@@ -77,6 +95,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fused_mlp_kernel(const MlpArgs a) 
   const T* __restrict__ W1p = (const T*)a.W1;
   const T* __restrict__ W2p = (const T*)a.W2c;
 
+  GCV_STAMP(0);
   for (int i = tid; i < 4 * C; i += NT) sB1[i] = a.b1[i];
 
   // x_ln fragments: k-step p, lane (token lr, half lh) holds k = 16p + 8lh .. +7
@@ -131,6 +150,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fused_mlp_kernel(const MlpArgs a) 
     stash(0, 1);
   }
   __syncthreads();
+  GCV_STAMP(1);
 
   for (int ch = 0; ch < NCH; ++ch) {
     if (!(GCV_MLP_ABLATE & 2) && ch + 1 < NCH) fetch(ch + 1, 0);
@@ -170,6 +190,7 @@ __global__ void __launch_bounds__(NW * 64, 2) fused_mlp_kernel(const MlpArgs a) 
       stash((ch + 1) & 1, 0);
       fetch(ch + 1, 1);
     }
+    if (ch == 0) GCV_STAMP(7);
     // ---- bias + GELU in registers, pack to 16-bit B-operand fragments, GEMM2 -----------------
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -206,8 +227,11 @@ __global__ void __launch_bounds__(NW * 64, 2) fused_mlp_kernel(const MlpArgs a) 
         }
       }
     }
+    if (ch == 0) GCV_STAMP(8);
     if (!(GCV_MLP_ABLATE & 2) && ch + 1 < NCH) stash((ch + 1) & 1, SPLIT ? 1 : 0);
+    if (ch == 0) GCV_STAMP(9);
     __syncthreads();
+    if (ch < 4) GCV_STAMP(2 + ch);
   }
 
   // ---- epilogue: (acc2 + b2) * gamma -> per-wave LDS tile [32 tokens][96 cols] fp32 -> + resid -> store
@@ -232,23 +256,31 @@ __global__ void __launch_bounds__(NW * 64, 2) fused_mlp_kernel(const MlpArgs a) 
     }
     __syncthreads();
     typedef T t4 __attribute__((ext_vector_type(4)));
+    // residual rows first, as 12 independent loads from clamped (always valid) addresses: inside the
+    // `row < M` branch each load waited out its own HBM latency (12 x ~1.2k cycles per workgroup)
+    t4 rres[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
       const int idx = lane + 64 * i;            // 32 rows x 24 four-channel pieces
       const int row = idx / 24, pc = idx - row * 24;
       const int64_t mm = m_wave + row;
-      if (mm < a.M) {
-        const f32x4 v = *(const f32x4*)(sC + row * 100 + 4 * pc);
-        const int64_t off = mm * C + half * 96 + 4 * pc;
-        const t4 r = *(const t4*)(Rp + off);
-        t4 o4;
+      const int64_t mmc = mm < a.M ? mm : (int64_t)a.M - 1;
+      rres[i] = *(const t4*)(Rp + mmc * C + half * 96 + 4 * pc);
+    }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o4[e] = from_f<T>(v[e] + to_f(r[e]));
-        *(t4*)(Op + off) = o4;
-      }
+    for (int i = 0; i < 12; ++i) {
+      const int idx = lane + 64 * i;
+      const int row = idx / 24, pc = idx - row * 24;
+      const int64_t mm = m_wave + row;
+      const f32x4 v = *(const f32x4*)(sC + row * 100 + 4 * pc);
+      t4 o4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o4[e] = from_f<T>(v[e] + to_f(rres[i][e]));
+      if (mm < a.M) *(t4*)(Op + mm * C + half * 96 + 4 * pc) = o4;
     }
     __syncthreads();
   }
+  GCV_STAMP(6);
 }
 
 template <typename T> int launch_fused_mlp(const MlpArgs& a, int C, hipStream_t s);

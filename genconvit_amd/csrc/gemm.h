@@ -334,7 +334,23 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   constexpr int ROWS = (EPI == EPI_POOL4) ? BM / 4 : BM;
   typedef T t4 __attribute__((ext_vector_type(4)));
   T* Cp = (T*)g.C;
-  for (int idx = tid; idx < ROWS * PPR; idx += 256) {
+  // the layer-scale residual is fetched first for all of this thread's pieces, from clamped (always
+  // valid) addresses, so the loads are independent instead of one exposed latency per guarded iteration
+  constexpr int NPIECES = (ROWS * PPR + 255) / 256;
+  t4 rres[EPI == EPI_RESID ? NPIECES : 1];
+  if (EPI == EPI_RESID) {
+#pragma unroll
+    for (int it = 0; it < NPIECES; ++it) {
+      const int idx = tid + it * 256;
+      const int rl = min(idx / PPR, ROWS - 1), pc = idx % PPR;
+      const int m = min(m0 + rl, g.M - 1), n = min(n0 + 4 * pc, g.N - 4);
+      rres[it] = *(const t4*)((const T*)g.resid + (int64_t)m * g.ldc + n);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NPIECES; ++it) {
+    const int idx = tid + it * 256;
+    if (idx >= ROWS * PPR) break;
     const int rl = idx / PPR, pc = idx - rl * PPR;
     const int n = n0 + 4 * pc;
     const int m = m0 + ((EPI == EPI_POOL4) ? 4 * rl : rl);
@@ -374,9 +390,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
       continue;
     }
     if (EPI == EPI_RESID) {
-      const t4 r = *(const t4*)((const T*)g.resid + o);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += to_f(r[e]);
+      for (int e = 0; e < 4; ++e) v[e] += to_f(rres[it][e]);
     }
     if (STAGE_F32 || EPI == EPI_POOL4) {
       t4 out = {from_f<T>(v[0]), from_f<T>(v[1]), from_f<T>(v[2]), from_f<T>(v[3])};
