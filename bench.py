@@ -98,6 +98,8 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--swin", action="store_true",
+                    help="also time the Swin-T embedder (row A6: constructed but never executed by the reference forward)")
     return ap.parse_args()
 
 
@@ -255,6 +257,25 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.net, sds, a.cpu_seconds)
 
+    swin = None
+    if rank == 0 and a.swin:
+        from genconvit_amd.model.swin import SwinTinyEmbedder
+        sw = SwinTinyEmbedder(init="empty")
+        sw.load_state_dict(synth.make_state_dict(spec.swin_tiny_spec(""), synth.DEFAULT_SEED, "swin/", device=device))
+        sw = sw.to(device).to(dtype).eval().reserve(a.batch)
+        for _ in range(max(a.warmup, 1)):
+            sw(x)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            sw(x)
+        torch.cuda.synchronize()
+        t_sw = (time.perf_counter() - t1) / a.steps
+        swin = {"note": "Swin-T embedder forward alone; NOT part of `value` (the reference never executes it in forward, "
+                        "SURVEY.md section 0.4)", "frames_per_s": round(a.batch / t_sw, 1), "ms_per_step": round(t_sw * 1e3, 3),
+                "frames_per_s_genconvit_plus_swin": round(a.batch / (t_sw + dt / a.steps), 1),
+                "algorithmic_gflop_per_frame": 8.98}
+
     if rank == 0:
         fps = n_global * a.steps / dt
         line = {
@@ -268,6 +289,8 @@ def main():
                        "parallelism": f"frame-shard x{world}", "algorithmic_gflop_per_frame": GFLOP_PER_FRAME[a.net]},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if swin is not None:
+            line["swin_embedder"] = swin
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

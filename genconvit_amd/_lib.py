@@ -54,6 +54,7 @@ SIGNATURES = {
     "gcv_convnext_forward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "gcv_swin_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "gcv_vote": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "gcv_preprocess": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gcv_profile_enable": (c_int, [c_void_p, c_int]),
     "gcv_profile_report": (c_char_p, [c_void_p]),
     "gcv_k_gemm": (c_int, [c_int, c_int, c_int, ctypes.POINTER(GemmArgs), c_void_p]),
@@ -270,6 +271,22 @@ class Handle:
 
     def profile_report(self):
         return json.loads((self.lib.gcv_profile_report(self._h) or b"[]").decode())
+
+
+def preprocess(frames_u8, dtype=None):
+    """Device-side ``preprocess_frame`` (model/pred_func.py:95-108): uint8 (N,H,W,3) device tensor ->
+    normalised (N,3,H,W) tensor of ``dtype`` (fp32 by default, like the reference)."""
+    import torch
+    lib = load()
+    dtype = dtype or torch.float32
+    if not (frames_u8.is_cuda and frames_u8.dtype == torch.uint8 and frames_u8.dim() == 4 and frames_u8.shape[3] == 3):
+        raise GenConViTHipError("preprocess expects a uint8 device tensor of shape (N,H,W,3)")
+    frames_u8 = frames_u8.contiguous()
+    n, h, w, _ = frames_u8.shape
+    out = torch.empty((n, 3, h, w), dtype=dtype, device=frames_u8.device)
+    check(lib.gcv_preprocess(dtype_code(dtype), frames_u8.data_ptr(), out.data_ptr(), n, h, w,
+                             current_stream_ptr(frames_u8.device)), "gcv_preprocess")
+    return out
 
 
 def vote(logits):

@@ -256,6 +256,10 @@ int gcv_k_mean_tokens(int dtype, const void* x, void* out, int nimg, int L, int 
   DISPATCH_DT(dtype, launch_mean_tokens<T>((const T*)x, (T*)out, nimg, L, C, (hipStream_t)s));
 }
 
+int gcv_preprocess(int dtype, const void* frames_u8_nhwc, void* out_nchw, int n, int H, int W, gcv_stream s) {
+  DISPATCH_DT(dtype, launch_preprocess<T>((const unsigned char*)frames_u8_nhwc, (T*)out_nchw, n, H, W, (hipStream_t)s));
+}
+
 // fused ConvNeXt MLP (16-bit only): W2 is given as plain (C,4C) fp32 on the device and packed here
 int gcv_k_fused_mlp(int dtype, int C, const void* x, const void* w1, const float* b1, const float* w2_f32,
                     const float* b2, const float* gamma, const void* resid, void* out, int M, gcv_stream s) {

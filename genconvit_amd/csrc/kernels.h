@@ -44,6 +44,7 @@ template <typename T> int launch_swin_window_attn(const T* qkv, const float* rpb
 template <typename T> int launch_patch_merge_ln(const T* x, const float* w, const float* b, T* out, int nimg, int H,
                                                 int W, int C, float eps, hipStream_t s);
 template <typename T> int launch_mean_tokens(const T* x, T* out, int nimg, int L, int C, hipStream_t s);
+template <typename T> int launch_preprocess(const unsigned char* u8, T* out, int n, int H, int W, hipStream_t s);
 int launch_kl(const float* partial, int splitk, const float* bias, const float* mu, float* rowsum, float* kl, int B,
               int N, hipStream_t s);
 int launch_vote(const float* logits, int rows, float* mean2, hipStream_t s);

@@ -1174,6 +1174,25 @@ static __global__ void __launch_bounds__(256) mse_finish_kernel(const float* __r
   if (threadIdx.x == 0) mse[b] = (red[0] + red[1] + red[2] + red[3]) * inv_count;
 }
 
+// ------------------------------------------------------------------ N1: fused preprocess_frame
+// uint8 NHWC (n,224,224,3) -> normalised NCHW in T: ((u8 / 255) - mean) / std, same op order as the reference
+// (model/pred_func.py:95-108: .float(), / 255.0, then transforms.Normalize of dataset/loader.py:63-65,77).
+template <typename T>
+__global__ void __launch_bounds__(256) preprocess_kernel(const unsigned char* __restrict__ u8, T* __restrict__ out,
+                                                         int64_t npix_total, int hw) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // pixel index over n*H*W
+  if (i >= npix_total) return;
+  const int64_t n = i / hw;
+  const int p = (int)(i - n * hw);
+  const float mean[3] = {0.485f, 0.456f, 0.406f};
+  const float stdv[3] = {0.229f, 0.224f, 0.225f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = (float)u8[i * 3 + c] / 255.0f;
+    out[(n * 3 + c) * hw + p] = from_f<T>((v - mean[c]) / stdv[c]);
+  }
+}
+
 // ------------------------------------------------------------------ K15 vote: mean over rows of sigmoid
 static __global__ void __launch_bounds__(256) vote_kernel(const float* __restrict__ logits, int rows,
                                                    float* __restrict__ mean2) {

@@ -245,6 +245,14 @@ template <typename T> int launch_mean_tokens(const T* x, T* out, int nimg, int L
   return 0;
 }
 
+template <typename T> int launch_preprocess(const unsigned char* u8, T* out, int n, int H, int W, hipStream_t s) {
+  GCV_REQUIRE(n > 0 && H > 0 && W > 0 && u8 && out, "preprocess: empty");
+  const int64_t total = (int64_t)n * H * W;
+  hipLaunchKernelGGL((preprocess_kernel<T>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, u8, out, total, H * W);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 #define GCV_INSTANTIATE_KERNELS(T)                                                                                    \
   template int launch_stem_ln<T>(const T*, int64_t, int64_t, int64_t, int64_t, const float*, const float*,            \
                                  const float*, const float*, T*, int, int, int, float, hipStream_t);                  \
@@ -261,6 +269,7 @@ template <typename T> int launch_mean_tokens(const T* x, T* out, int nimg, int L
   template int launch_resize_mse<T>(const T*, const T*, T*, float*, float*, int, hipStream_t);                        \
   template int launch_swin_window_attn<T>(const T*, const float*, T*, int, int, int, int, int, int, hipStream_t);     \
   template int launch_patch_merge_ln<T>(const T*, const float*, const float*, T*, int, int, int, int, float, hipStream_t); \
-  template int launch_mean_tokens<T>(const T*, T*, int, int, int, hipStream_t);
+  template int launch_mean_tokens<T>(const T*, T*, int, int, int, hipStream_t);                                   \
+  template int launch_preprocess<T>(const unsigned char*, T*, int, int, int, hipStream_t);
 
 }  // namespace gcv

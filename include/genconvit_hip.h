@@ -85,6 +85,10 @@ int gcv_convnext_forward(gcv_handle* h, int which, const void* x_nchw, int batch
  * model/model_embedder.py:22): x (B,3,224,224) -> (B,1000) in the handle dtype. */
 int gcv_swin_forward(gcv_handle* h, const void* x_nchw, int batch, void* logits1000, gcv_stream stream);
 
+/* preprocess_frame (model/pred_func.py:95-108 + the "vid" Normalize of dataset/loader.py:63-65,77) on the device:
+ * uint8 NHWC face crops (n,H,W,3) -> ((x/255) - mean) / std as NCHW in `dtype` (row N1 of SURVEY.md §8f). */
+int gcv_preprocess(int dtype, const void* frames_u8_nhwc, void* out_nchw, int n, int H, int W, gcv_stream s);
+
 /* pred_vid's reduction (model/pred_func.py:120,125): mean2[c] = mean_r sigmoid(logits[r][c]). */
 int gcv_vote(const float* logits, int rows, float* mean2, gcv_stream stream);
 

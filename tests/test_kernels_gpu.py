@@ -441,3 +441,17 @@ def test_gemm_lds_dma_pipeline_residual(dt, M, N, K):
     gemm(dtype, _lib.A_PLAIN, _lib.EPI_RESID, D(A, dtype), D(W, dtype), Xd, M, N, K, lda=K, ldc=N, bias=D(bias),
          gamma=D(gamma), resid=Xd)
     assert_close(Xd, X + gamma * (A @ W.t() + bias), tol(dtype, 2.0), "glds gemm resid")
+
+
+def test_preprocess_frame_on_device_matches_reference_semantics():
+    """Row N1: uint8 NHWC -> normalised NCHW (model/pred_func.py:95-108, dataset/loader.py:63-65,77)."""
+    from genconvit_amd import synth
+    from genconvit_amd.model import pred_func
+    from oracle import cpu_ref
+    u8 = synth.make_uint8_frames(3)
+    want = cpu_ref.preprocess_frame(u8.numpy())
+    got = _lib.preprocess(u8.to(dev()))
+    assert got.dtype == torch.float32 and got.shape == (3, 3, 224, 224)
+    assert_close(got, want, 1e-6, "preprocess fp32")
+    assert_close(_lib.preprocess(u8.to(dev()), torch.float16), want, 2e-3, "preprocess fp16")
+    assert_close(pred_func.preprocess_frame(u8.numpy()), want, 1e-6, "preprocess_frame drop-in")
