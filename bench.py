@@ -98,6 +98,7 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-concurrent", action="store_true", help="run ED and VAE back to back on one stream (A/B switch)")
     ap.add_argument("--swin", action="store_true",
                     help="also time the Swin-T embedder (row A6: constructed but never executed by the reference forward)")
     return ap.parse_args()
@@ -169,6 +170,7 @@ def main():
     log(f"host cores usable: {host_cores()} (os.cpu_count() = {os.cpu_count()})")
 
     dtype = DT[a.dtype]
+    GenConViT.concurrent = not a.no_concurrent
     nets = 2 if a.net == "genconvit" else 1
     model, sds = build_models(a.net, dtype, a.batch, device)
     log("models built (synthetic weights generated on device)")
@@ -213,7 +215,8 @@ def main():
         handles = [m._handle for m in (getattr(model, "model_ed", None), getattr(model, "model_vae", None)) if m is not None]
         for h in handles:
             h.profile_enable(True)
-        agg = {}
+        GenConViT.concurrent = False     # per-kernel durations are taken with the two networks back to back:
+        agg = {}                         # overlapped launches would time each kernel while it shares the GPU
         for _ in range(max(a.profile_steps, 1)):
             step()
             torch.cuda.synchronize()
@@ -224,6 +227,7 @@ def main():
                         g[k] += r[k]
         for h in handles:
             h.profile_enable(False)
+        GenConViT.concurrent = not a.no_concurrent
         total_ms = sum(v["ms"] for v in agg.values())
         # kernel families: every pointwise-MLP contraction of the ConvNeXt blocks runs on the MFMA GEMM
         # templates (gemm_glds_kernel / gemm_kernel with plain A, and the fused two-GEMM MLP kernel)

@@ -129,36 +129,41 @@ dwconv7_ln_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*[49][
     xmask[s] = (ix >= 0 && ix < W) ? 1.0f : 0.0f;
     xoff[s] = min(max(ix, 0), W - 1) * C;
   }
-  float vn[13];
-  {
-    const int iy = y0 - 3;
-    const float rmask = (iy >= 0 && iy < H) ? 1.0f : 0.0f;
-    const T* rp = xb + (int64_t)min(max(iy, 0), H - 1) * W * C;
+  // The halo window is loaded in batches of RB rows (5+5+3, or 2-row batches at C=768 where 12 waves per
+  // workgroup cap the register file at 168): all loads of a batch are independent and
+  // in flight together, then its FMAs run.  (A row-by-row prefetch exposed one memory latency per row:
+  // at the 14x14 / 7x7 stages there are only 512 / 128 workgroups, nothing else hides it.)
+  constexpr int RB = (C == 768) ? 2 : 5;
 #pragma unroll
-    for (int s = 0; s < 13; ++s) vn[s] = to_f(rp[xoff[s]]) * (rmask * xmask[s]);
-  }
+  for (int rb = 0; rb < 13; rb += RB) {
+    float v[RB][13];
 #pragma unroll
-  for (int r = 0; r < 13; ++r) {
-    float v[13];
+    for (int rr = 0; rr < RB; ++rr) {
+      const int r = rb + rr;
+      if (r < 13) {
+        const int iy = y0 + r - 3;
+        const float rmask = (iy >= 0 && iy < H) ? 1.0f : 0.0f;
+        const T* rp = xb + (int64_t)min(max(iy, 0), H - 1) * W * C;
 #pragma unroll
-    for (int s = 0; s < 13; ++s) v[s] = vn[s];
-    if (r + 1 < 13) {
-      const int iy = y0 + r - 2;
-      const float rmask = (iy >= 0 && iy < H) ? 1.0f : 0.0f;
-      const T* rp = xb + (int64_t)min(max(iy, 0), H - 1) * W * C;
-#pragma unroll
-      for (int s = 0; s < 13; ++s) vn[s] = to_f(rp[xoff[s]]) * (rmask * xmask[s]);
+        for (int s = 0; s < 13; ++s) v[rr][s] = to_f(rp[xoff[s]]) * (rmask * xmask[s]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int ky = 0; ky < 7; ++ky) {
+    for (int rr = 0; rr < RB; ++rr) {
+      const int r = rb + rr;
+      if (r < 13) {
 #pragma unroll
-      for (int sx = 0; sx < 13; ++sx) {
+        for (int ky = 0; ky < 7; ++ky) {
 #pragma unroll
-        for (int kx = 0; kx < 7; ++kx) {
-          const int oy = r - ky, ox = sx - kx;
-          if (oy >= 0 && oy < 7 && ox >= 0 && ox < 7)
-            acc[oy * 7 + ox] = fmaf(v[sx], w[ky * 7 + kx], acc[oy * 7 + ox]);
+          for (int sx = 0; sx < 13; ++sx) {
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+              const int oy = r - ky, ox = sx - kx;
+              if (oy >= 0 && oy < 7 && ox >= 0 && ox < 7)
+                acc[oy * 7 + ox] = fmaf(v[rr][sx], w[ky * 7 + kx], acc[oy * 7 + ox]);
+            }
+          }
         }
       }
     }

@@ -23,6 +23,9 @@ def _read_checkpoint(name):
 
 
 class GenConViT(nn.Module):
+    concurrent = True        # run ED and VAE on two streams when net is the ensemble (class-level switch)
+    _streams = None
+
     def __init__(self, config, ed, vae, net, fp16):
         super().__init__()
         self.net = net
@@ -67,6 +70,29 @@ class GenConViT(nn.Module):
             return self.model_ed(x)
         if self.net == "vae":
             return self.model_vae(x, eps=eps, want_recon=False)[0]
+        if x.is_cuda and self.concurrent:
+            # ED and VAE are independent until the concat: each network has its own handle / workspace, so
+            # they run on two HIP streams and the GPU overlaps one network's small-grid kernels (14x14 and
+            # 7x7 stages, heads) with the other's instead of draining between launches
+            cur = torch.cuda.current_stream(x.device)
+            if self._streams is None or self._streams[0].device != x.device:
+                self._streams = (torch.cuda.Stream(x.device), torch.cuda.Stream(x.device))
+            s_ed, s_vae = self._streams
+            s_ed.wait_stream(cur)
+            s_vae.wait_stream(cur)
+            with torch.cuda.stream(s_ed):
+                x1 = self.model_ed(x)
+            with torch.cuda.stream(s_vae):
+                x2 = self.model_vae(x, eps=eps, want_recon=False)[0]
+            cur.wait_stream(s_ed)
+            cur.wait_stream(s_vae)
+            x.record_stream(s_ed)
+            x.record_stream(s_vae)
+            if eps is not None:
+                eps.record_stream(s_vae)
+            x1.record_stream(cur)
+            x2.record_stream(cur)
+            return torch.cat((x1, x2), dim=0)
         x1 = self.model_ed(x)
         x2 = self.model_vae(x, eps=eps, want_recon=False)[0]
         return torch.cat((x1, x2), dim=0)
