@@ -12,6 +12,7 @@
 //   K15 sigmoid -> mean over rows               vote_kernel
 #pragma once
 #include "common.h"
+#include "gemm.h"
 
 namespace gcv {
 
@@ -848,6 +849,177 @@ __global__ void __launch_bounds__(64) swin_window_attn_kernel(const T* __restric
     T* dst = out + tok * C + head * 32;
 #pragma unroll
     for (int d = 0; d < 32; ++d) dst[d] = from_f<T>(o[d] * inv);
+  }
+}
+
+// ------------------------------------------------------------------ K16 (16-bit): window attention on MFMA
+// One wave per (window, head); the 49 tokens are padded to 64.
+//   S^T = K . Q^T   : v_mfma_f32_32x32x16, A = K fragments (rows = keys), B = Q fragments (cols = queries)
+//                     -> key on registers, QUERY ON THE LANE (2x2 tiles of 32x32, 8 MFMAs)
+//   softmax         : scale, + relative-position bias (LDS table) + shift mask, row max / sum = in-lane over
+//                     32 registers + one cross-half exchange; padded keys masked out
+//   O^T = V^T . P^T : the probability accumulators are packed to 16-bit and used directly as the B operand
+//                     (guide: "an accumulator tile as the next MFMA's operand"); V^T fragments come from an LDS
+//                     image [d][key] whose key axis is pre-permuted to the accumulator's k order (8 MFMAs)
+// K and Q tiles live in LDS as [token][32] rows (64 B) read with ds_read_b128.
+template <typename T>
+__global__ void __launch_bounds__(64) swin_window_attn_mfma_kernel(const T* __restrict__ qkv,
+                                                                  const float* __restrict__ rpb, T* __restrict__ out,
+                                                                  int H, int W, int C, int nH, int shift,
+                                                                  float scale) {
+  static_assert(sizeof(T) == 2, "MFMA window attention is built for 16-bit storage");
+  __shared__ __attribute__((aligned(16))) unsigned short sQ[64 * 32];
+  __shared__ __attribute__((aligned(16))) unsigned short sK[64 * 32];
+  __shared__ __attribute__((aligned(16))) unsigned short sVt[32 * 64];    // [d][permuted key]
+  __shared__ float sB[169];
+  const int lane = threadIdx.x;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int head = blockIdx.y;
+  const int nWx = W / 7, nWy = H / 7;
+  const int win = blockIdx.x % (nWx * nWy);
+  const int b = blockIdx.x / (nWx * nWy);
+  const int wy = win / nWx, wx = win - wy * nWx;
+
+  for (int i = lane; i < 169; i += 64) sB[i] = rpb[i * nH + head];
+  // ---- stage Q, K rows and V^T (token = lane; padded tokens 49..63 are zero) ----
+  {
+    const bool live = lane < 49;
+    const int ty = live ? lane / 7 : 0, tx = live ? lane - (lane / 7) * 7 : 0;
+    const int yo = (wy * 7 + ty + shift) % H, xo = (wx * 7 + tx + shift) % W;
+    const int64_t tok = ((int64_t)b * H + yo) * W + xo;
+    const T* base = qkv + tok * 3 * C + head * 32;
+    u32x4 q4[4], k4[4], v4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      q4[c] = live ? *(const u32x4*)(base + 8 * c) : z;
+      k4[c] = live ? *(const u32x4*)(base + C + 8 * c) : z;
+      v4[c] = live ? *(const u32x4*)(base + 2 * C + 8 * c) : z;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      *(u32x4*)(sQ + lane * 32 + 8 * c) = q4[c];
+      *(u32x4*)(sK + lane * 32 + 8 * c) = k4[c];
+    }
+    // V^T with the key axis in accumulator order: key = 32 kt + 16 s + 8 a + 4 h + e  ->  32 kt + 16 s + 8 h + 4 a + e
+    const int kt = lane >> 5, s = (lane >> 4) & 1, a = (lane >> 3) & 1, hh = (lane >> 2) & 1, e = lane & 3;
+    const int pk = 32 * kt + 16 * s + 8 * hh + 4 * a + e;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        sVt[(8 * c + 2 * w) * 64 + pk] = (unsigned short)(v4[c][w] & 0xffffu);
+        sVt[(8 * c + 2 * w + 1) * 64 + pk] = (unsigned short)(v4[c][w] >> 16);
+      }
+  }
+  __syncthreads();
+
+  // ---- S^T = K . Q^T ----
+  f32x16 sacc[2][2];               // [key tile][query tile]
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kt][qt][r] = 0.0f;
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {             // d = 16 st + 8 lh .. +7
+    u32x4 kf[2], qf[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      kf[t] = *(const u32x4*)(sK + (32 * t + lr) * 32 + 16 * st + 8 * lh);
+      qf[t] = *(const u32x4*)(sQ + (32 * t + lr) * 32 + 16 * st + 8 * lh);
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) Mfma<T>::run(kf[kt], qf[qt], sacc[kt][qt]);
+  }
+
+  // ---- softmax over keys, per query (query = 32 qt + lr on this lane; keys split over registers and halves) ----
+  u32x4 pf[2][2][2];               // [query tile][key tile][k-step] packed probabilities (B operand of P.V)
+  float inv_sum[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int qi = 32 * qt + lr;
+    const int qy = qi / 7, qx = qi - qy * 7;                    // (garbage for padded queries, never stored)
+    const int qys = wy * 7 + qy, qxs = wx * 7 + qx;
+    const int qreg = (qys < H - 7 ? 0 : (qys < H - shift ? 1 : 2)) * 3 + (qxs < W - 7 ? 0 : (qxs < W - shift ? 1 : 2));
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kj = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float v = sacc[kt][qt][r] * scale;
+        if (kj < 49 && qi < 49) {
+          const int ky = kj / 7, kx = kj - ky * 7;
+          v += sB[(qy - ky + 6) * 13 + (qx - kx + 6)];
+          if (shift) {
+            const int kys = wy * 7 + ky, kxs = wx * 7 + kx;
+            const int kreg = (kys < H - 7 ? 0 : (kys < H - shift ? 1 : 2)) * 3 + (kxs < W - 7 ? 0 : (kxs < W - shift ? 1 : 2));
+            if (kreg != qreg) v -= 100.0f;
+          }
+        } else if (kj >= 49) {
+          v = -3.0e38f;                                          // padded key: exp() -> 0
+        }
+        sacc[kt][qt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.0f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __expf(sacc[kt][qt][r] - mx);
+        sacc[kt][qt][r] = p;
+        sum += p;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    inv_sum[qt] = 1.0f / sum;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const uint32_t lo = bits16<T>(sacc[kt][qt][8 * s + 2 * w]);
+          const uint32_t hi = bits16<T>(sacc[kt][qt][8 * s + 2 * w + 1]);
+          pf[qt][kt][s][w] = lo | (hi << 16);
+        }
+  }
+
+  // ---- O^T = V^T . P^T : rows = d (registers), cols = query (lane) ----
+  f32x16 oacc[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[qt][r] = 0.0f;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const u32x4 vf = *(const u32x4*)(sVt + lr * 64 + 32 * kt + 16 * s + 8 * lh);   // A: row d = lr, 8 permuted keys
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) Mfma<T>::run(vf, pf[qt][kt][s], oacc[qt]);
+    }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int qi = 32 * qt + lr;
+    if (qi < 49) {
+      const int qy = qi / 7, qx = qi - qy * 7;
+      const int yo = (wy * 7 + qy + shift) % H, xo = (wx * 7 + qx + shift) % W;
+      T* dst = out + (((int64_t)b * H + yo) * W + xo) * C + head * 32;
+      typedef T t4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        t4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = from_f<T>(oacc[qt][4 * g4 + e] * inv_sum[qt]);
+        *(t4*)(dst + 8 * g4 + 4 * lh) = o;
+      }
+    }
   }
 }
 

@@ -221,6 +221,15 @@ int launch_swin_window_attn(const T* qkv, const float* rpb, T* out, int nimg, in
   GCV_REQUIRE(H % 7 == 0 && W % 7 == 0 && C == nH * 32 && nimg > 0, "swin attention: 7x7 windows, head_dim 32");
   GCV_REQUIRE(shift == 0 || (shift == 3 && H > 7), "swin attention: shift is 0 or 3");
   const float scale = 0.17677669529663689f;   // 32^-0.5
+  if constexpr (sizeof(T) == 2) {
+    static const bool valu_only = std::getenv("GCV_SWIN_ATTN_VALU") != nullptr;   // A/B switch
+    if (!valu_only && (reinterpret_cast<uintptr_t>(qkv) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && C % 8 == 0) {
+      hipLaunchKernelGGL((swin_window_attn_mfma_kernel<T>), dim3(nimg * (H / 7) * (W / 7), nH), dim3(64), 0, s, qkv, rpb,
+                         out, H, W, C, nH, shift, scale);
+      GCV_CHECK_HIP(hipGetLastError());
+      return 0;
+    }
+  }
   hipLaunchKernelGGL((swin_window_attn_kernel<T>), dim3(nimg * (H / 7) * (W / 7), nH), dim3(64), 0, s, qkv, rpb, out,
                      H, W, C, nH, shift, scale);
   GCV_CHECK_HIP(hipGetLastError());
