@@ -55,6 +55,7 @@ SIGNATURES = {
     "gcv_swin_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "gcv_vote": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "gcv_preprocess": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "gcv_vote_segments": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "gcv_profile_enable": (c_int, [c_void_p, c_int]),
     "gcv_profile_report": (c_char_p, [c_void_p]),
     "gcv_k_gemm": (c_int, [c_int, c_int, c_int, ctypes.POINTER(GemmArgs), c_void_p]),
@@ -286,6 +287,20 @@ def preprocess(frames_u8, dtype=None):
     out = torch.empty((n, 3, h, w), dtype=dtype, device=frames_u8.device)
     check(lib.gcv_preprocess(dtype_code(dtype), frames_u8.data_ptr(), out.data_ptr(), n, h, w,
                              current_stream_ptr(frames_u8.device)), "gcv_preprocess")
+    return out
+
+
+def vote_segments(logits, batch, nets, offsets):
+    """Per-video ``mean(sigmoid(logits), dim=0)`` for several videos batched in one forward (row N3):
+    ``offsets`` = int32 device tensor of n_videos+1 frame offsets; returns (n_videos, 2) fp32."""
+    import torch
+    lib = load()
+    logits = logits.float().contiguous()
+    offsets = offsets.to(device=logits.device, dtype=torch.int32).contiguous()
+    nvid = offsets.numel() - 1
+    out = torch.empty((nvid, 2), dtype=torch.float32, device=logits.device)
+    check(lib.gcv_vote_segments(logits.data_ptr(), int(batch), int(nets), offsets.data_ptr(), nvid, out.data_ptr(),
+                                current_stream_ptr(logits.device)), "gcv_vote_segments")
     return out
 
 

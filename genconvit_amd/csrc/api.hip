@@ -133,6 +133,11 @@ int gcv_vote(const float* logits, int rows, float* mean2, gcv_stream stream) {
   return launch_vote(logits, rows, mean2, (hipStream_t)stream);
 }
 
+int gcv_vote_segments(const float* logits, int batch, int nets, const int* offsets, int n_videos, float* mean2,
+                      gcv_stream stream) {
+  return launch_vote_segments(logits, batch, nets, offsets, n_videos, mean2, (hipStream_t)stream);
+}
+
 size_t gcv_workspace_bytes(const gcv_handle* h) { return h ? h->net->workspace_bytes() : 0; }
 
 int gcv_profile_enable(gcv_handle* h, int on) {

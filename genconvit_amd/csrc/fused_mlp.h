@@ -200,9 +200,11 @@ __global__ void __launch_bounds__(NW * 64, 2) fused_mlp_kernel(const MlpArgs a) 
         const f32x4 bv = *(const f32x4*)(sB1 + ch * HC + 32 * j + 8 * q + 4 * lh);
         typedef T t4 __attribute__((ext_vector_type(4)));
         t4 h4;
+        float hv[4] = {acc1[j][4 * q], acc1[j][4 * q + 1], acc1[j][4 * q + 2], acc1[j][4 * q + 3]};
+        if (GCV_MLP_ABLATE & 1) bias_act4<ACT_NONE, T>(hv, bv);
+        else bias_act4<ACT_GELU, T>(hv, bv);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          h4[e] = from_f<T>((GCV_MLP_ABLATE & 1) ? (acc1[j][4 * q + e] + bv[e]) : act_fn<ACT_GELU>(acc1[j][4 * q + e] + bv[e]));
+        for (int e = 0; e < 4; ++e) h4[e] = from_f<T>(hv[e]);
         const uint2 pk = __builtin_bit_cast(uint2, h4);
         hf[q >> 1][2 * (q & 1)] = pk.x;
         hf[q >> 1][2 * (q & 1) + 1] = pk.y;

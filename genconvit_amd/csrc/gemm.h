@@ -89,6 +89,46 @@ template <int ACT> __device__ __forceinline__ float act_fn(float x) {
   return x;
 }
 
+/// GELU for the 16-bit storage paths, four values at a time on the packed fp32 pipe (v_pk_fma_f32: two lanes of
+// work per issue slot).  The A&S form above costs ~13 VALU + 2 quarter-rate transcendentals per value and made the
+// hidden-layer epilogues VALU-bound; here
+//     gelu(x) = max(x, 0) - h(min(|x|, 4.5)),   h(a) = a * 0.5 * erfc(a / sqrt 2)
+// with h a degree-10 minimax polynomial in t = a * (2/4.5) - 1 (fit in profiles/gelu_fit.py; |error| <= 1.5e-5
+// over all x, i.e. 30x below the fp16 rounding step of the stored result; h(4.5) = 1.5e-5 is the tail that is cut).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float c) { return (f32x2){c, c}; }
+__device__ __forceinline__ f32x2 gelu_pk(f32x2 x) {
+  const f32x2 a = {fminf(fabsf(x[0]), 4.5f), fminf(fabsf(x[1]), 4.5f)};
+  const f32x2 t = __builtin_elementwise_fma(a, splat2(0.44444444444f), splat2(-1.0f));
+  f32x2 p = splat2(-4.258673483e-02f);
+  p = __builtin_elementwise_fma(p, t, splat2(2.178248281e-02f));
+  p = __builtin_elementwise_fma(p, t, splat2(1.763803063e-01f));
+  p = __builtin_elementwise_fma(p, t, splat2(-1.763150062e-01f));
+  p = __builtin_elementwise_fma(p, t, splat2(-2.049071560e-01f));
+  p = __builtin_elementwise_fma(p, t, splat2(4.347813707e-01f));
+  p = __builtin_elementwise_fma(p, t, splat2(-2.029683018e-01f));
+  p = __builtin_elementwise_fma(p, t, splat2(-1.472158060e-01f));
+  p = __builtin_elementwise_fma(p, t, splat2(2.465923971e-01f));
+  p = __builtin_elementwise_fma(p, t, splat2(-1.330395067e-01f));
+  p = __builtin_elementwise_fma(p, t, splat2(2.749713404e-02f));
+  const f32x2 r = {fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
+  return r - p;
+}
+
+// v[e] = act(v[e] + b[e]) for four consecutive channels; 16-bit storage takes the packed GELU
+template <int ACT, typename T> __device__ __forceinline__ void bias_act4(float (&v)[4], const f32x4 b) {
+#ifndef GCV_GELU_EXACT
+  if (ACT == ACT_GELU && sizeof(T) == 2) {
+    const f32x2 lo = gelu_pk((f32x2){v[0], v[1]} + (f32x2){b[0], b[1]});
+    const f32x2 hi = gelu_pk((f32x2){v[2], v[3]} + (f32x2){b[2], b[3]});
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+    return;
+  }
+#endif
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = act_fn<ACT>(v[e] + b[e]);
+}
+
 // staged-row length (dwords) of the epilogue tile: BN elements + a pad that makes the 32 token rows a
 // wave writes land on distinct banks (fp32: stride = 4*odd for ds_write_b128, 16-bit: 2*odd for b64)
 template <int BN, bool F32> struct StageRow { static constexpr int dwords = F32 ? BN + 4 : BN / 2 + 2; };
@@ -311,10 +351,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
             if (g.bias) bv = *(const f32x4*)(g.bias + bi);
             if (EPI == EPI_RESID) gv = *(const f32x4*)(g.gamma + n);
           }
+          bias_act4<ACT, T>(v, bv);
+          if (EPI == EPI_RESID) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] = act_fn<ACT>(v[e] + bv[e]);
-            if (EPI == EPI_RESID) v[e] *= gv[e];
+            for (int e = 0; e < 4; ++e) v[e] *= gv[e];
           }
         }
         if (STAGE_F32) {

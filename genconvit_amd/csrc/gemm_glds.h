@@ -150,9 +150,8 @@ __global__ void __launch_bounds__(256, 2) gemm_glds_kernel(const GemmArgs g) {
         const int n = n0 + nl;
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (g.bias) bv = *(const f32x4*)(g.bias + n);
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_fn<ACT>(acc[i][j][4 * q + e] + bv[e]);
+        float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        bias_act4<ACT, T>(v, bv);
         if (EPI == EPI_RESID) {
           const f32x4 gv = *(const f32x4*)(g.gamma + n);
           const int64_t mm = m < g.M ? m : g.M - 1;

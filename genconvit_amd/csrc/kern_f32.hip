@@ -15,4 +15,10 @@ int launch_vote(const float* logits, int rows, float* mean2, hipStream_t s) {
   GCV_CHECK_HIP(hipGetLastError());
   return 0;
 }
+int launch_vote_segments(const float* logits, int B, int nets, const int* off, int nvid, float* mean2, hipStream_t s) {
+  GCV_REQUIRE(logits && off && mean2 && B > 0 && nvid > 0 && (nets == 1 || nets == 2), "vote_segments: bad arguments");
+  hipLaunchKernelGGL(vote_segments_kernel, dim3(nvid), dim3(64), 0, s, logits, B, nets, off, mean2);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 }  // namespace gcv

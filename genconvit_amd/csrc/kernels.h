@@ -48,5 +48,6 @@ template <typename T> int launch_preprocess(const unsigned char* u8, T* out, int
 int launch_kl(const float* partial, int splitk, const float* bias, const float* mu, float* rowsum, float* kl, int B,
               int N, hipStream_t s);
 int launch_vote(const float* logits, int rows, float* mean2, hipStream_t s);
+int launch_vote_segments(const float* logits, int B, int nets, const int* off, int nvid, float* mean2, hipStream_t s);
 
 }  // namespace gcv

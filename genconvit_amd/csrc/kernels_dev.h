@@ -1389,4 +1389,28 @@ static __global__ void __launch_bounds__(256) vote_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------ N3: per-video vote over a batched forward
+// Several videos' frames are concatenated into one batch; logits rows are [net0 frames 0..B-1; net1 frames ...]
+// (model/genconvit.py:74).  Video v owns frames [off[v], off[v+1]): mean2[v][c] = mean over its frames and nets of
+// sigmoid(logit[.][c])  == max_prediction_value's mean(dim=0) applied per video (model/pred_func.py:120,125).
+static __global__ void __launch_bounds__(64) vote_segments_kernel(const float* __restrict__ logits, int B, int nets,
+                                                                  const int* __restrict__ off, float* __restrict__ mean2) {
+  const int v = blockIdx.x, lane = threadIdx.x;
+  const int lo = off[v], hi = off[v + 1];
+  float s0 = 0.0f, s1 = 0.0f;
+  for (int n = 0; n < nets; ++n)
+    for (int f = lo + lane; f < hi; f += 64) {
+      const int r = n * B + f;
+      s0 += 1.0f / (1.0f + expf(-logits[2 * r]));
+      s1 += 1.0f / (1.0f + expf(-logits[2 * r + 1]));
+    }
+  s0 = wave_sum(s0);
+  s1 = wave_sum(s1);
+  if (lane == 0) {
+    const float cnt = (float)(nets * (hi - lo));
+    mean2[2 * v] = cnt > 0 ? s0 / cnt : 0.5f;
+    mean2[2 * v + 1] = cnt > 0 ? s1 / cnt : 0.5f;
+  }
+}
+
 }  // namespace gcv

@@ -59,6 +59,34 @@ def pred_vid(df, model):
         return max_prediction_value(torch.sigmoid(model(df).squeeze()))
 
 
+def pred_vids(dfs, model, max_batch=128):
+    """Row N3: the reference calls the model once per video with <= 15 frames
+    (prediction.py:231-266); here the face crops of MANY videos are concatenated into batches of up to
+    ``max_batch`` frames, run through one forward each, and voted per video on the device.  Returns
+    ``[(y, y_val), ...]`` with the exact ``pred_vid`` semantics per video."""
+    results = [None] * len(dfs)
+    order = [i for i, d in enumerate(dfs) if len(d) >= 1]
+    p = next(model.parameters())
+    nets = 2 if getattr(model, "net", "genconvit") not in ("ed", "vae") else 1
+    i = 0
+    with torch.no_grad():
+        while i < len(order):
+            group, n = [], 0
+            while i < len(order) and (not group or n + len(dfs[order[i]]) <= max_batch):
+                group.append(order[i])
+                n += len(dfs[order[i]])
+                i += 1
+            batch = torch.cat([dfs[g].to(p.device) for g in group])
+            offs = torch.tensor([0] + list(np.cumsum([len(dfs[g]) for g in group])), dtype=torch.int32)
+            logits = model(batch)
+            means = _lib.vote_segments(logits, batch.shape[0], nets, offs).cpu()
+            for k, g in enumerate(group):
+                m = means[k]
+                results[g] = (int(torch.argmax(m).item()),
+                              m[0].item() if m[0] > m[1] else abs(1 - m[1]).item())
+    return results
+
+
 def max_prediction_value(y_pred):
     """reference :123-131 (the device-side reduction is ``genconvit_amd._lib.vote``)."""
     mean_val = torch.mean(y_pred, dim=0)

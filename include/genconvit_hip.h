@@ -92,6 +92,12 @@ int gcv_preprocess(int dtype, const void* frames_u8_nhwc, void* out_nchw, int n,
 /* pred_vid's reduction (model/pred_func.py:120,125): mean2[c] = mean_r sigmoid(logits[r][c]). */
 int gcv_vote(const float* logits, int rows, float* mean2, gcv_stream stream);
 
+/* Row N3: the same vote for several videos batched into ONE forward.  logits rows are [net 0 frames 0..B-1; net 1 ...]
+ * (model/genconvit.py:74); video v owns frames [offsets[v], offsets[v+1]) (int32 device array of n_videos+1 entries);
+ * mean2[v][c] = mean over its frames and nets of sigmoid(logit[.][c]) — what max_prediction_value reduces per video. */
+int gcv_vote_segments(const float* logits, int batch, int nets, const int* offsets, int n_videos, float* mean2,
+                      gcv_stream stream);
+
 /* Per-launch timing with HIP events on the launch stream.  After gcv_profile_enable(h,1) every
  * kernel launch of the following forwards is bracketed by events; gcv_profile_report() waits for
  * them and returns a JSON array aggregated by op tag (launches, ms, algorithmic flops / bytes)

@@ -243,3 +243,38 @@ def test_swin_tiny_16bit_delta(dtype, bound):
     err = (got - cpu_ref.swin_tiny(sd, "", x)).abs().max().item()
     print(f"\nSwin-T {dtype}: max |logits1000 diff vs fp32 oracle| = {err:.3e}")
     assert err <= bound
+
+
+# ----------------------------------------------------------------------------- row N3: several videos per forward
+def test_pred_vids_batches_videos_and_votes_per_video():
+    """One forward over the concatenated crops of several videos + per-video device vote == pred_vid per video."""
+    lens = [4, 1, 6, 0, 3]
+    total = sum(lens)
+    eps_all = synth.make_eps(total, name="n3").cuda()
+    x = synth.make_frames(total, name="n3")
+    g = GenConViT.from_modules(ed_model(), vae_model(), net="genconvit")
+    fwd = g.forward
+    state = {"o": 0}
+
+    def pinned(df):                      # frame f always sees eps_all[f], batched or not
+        o = state["o"]
+        state["o"] += df.shape[0]
+        return fwd(df, eps=eps_all[o:o + df.shape[0]])
+    g.forward = pinned
+    dfs, o = [], 0
+    for n in lens:
+        dfs.append(x[o:o + n])
+        o += n
+    want = [pred_func.pred_vid(d, g) if len(d) else None for d in dfs]
+    for max_batch in (128, 5):           # one forward for all / groups split at video boundaries
+        state["o"] = 0
+        got = pred_func.pred_vids(dfs, g, max_batch=max_batch)
+        assert got[3] is None
+        for gv, wv in zip(got, want):
+            if wv is not None:
+                assert gv[0] == wv[0] and abs(gv[1] - wv[1]) <= 1e-5
+    g1 = GenConViT.from_modules(ed_model(), None, net="ed")
+    got = pred_func.pred_vids([dfs[0], dfs[2]], g1)
+    for gv, d in zip(got, (dfs[0], dfs[2])):
+        wv = pred_func.pred_vid(d, g1)
+        assert gv[0] == wv[0] and abs(gv[1] - wv[1]) <= 1e-5
