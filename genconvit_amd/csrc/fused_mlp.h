@@ -195,19 +195,27 @@ __global__ void __launch_bounds__(NW * 64, 2) fused_mlp_kernel(const MlpArgs a) 
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       u32x4 hf[2];
+      constexpr int QB = (C == 96) ? 2 : 1;            // channel groups per batch: 2*QB independent GELU chains
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 bv = *(const f32x4*)(sB1 + ch * HC + 32 * j + 8 * q + 4 * lh);
-        typedef T t4 __attribute__((ext_vector_type(4)));
-        t4 h4;
-        float hv[4] = {acc1[j][4 * q], acc1[j][4 * q + 1], acc1[j][4 * q + 2], acc1[j][4 * q + 3]};
-        if (GCV_MLP_ABLATE & 1) bias_act4<ACT_NONE, T>(hv, bv);
-        else bias_act4<ACT_GELU, T>(hv, bv);
+      for (int q0 = 0; q0 < 4; q0 += QB) {             // (C = 192 has no registers to spare for four)
+        float hv[QB][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) h4[e] = from_f<T>(hv[e]);
-        const uint2 pk = __builtin_bit_cast(uint2, h4);
-        hf[q >> 1][2 * (q & 1)] = pk.x;
-        hf[q >> 1][2 * (q & 1) + 1] = pk.y;
+        for (int qq = 0; qq < QB; ++qq) {
+          const int q = q0 + qq;
+          const f32x4 bv = *(const f32x4*)(sB1 + ch * HC + 32 * j + 8 * q + 4 * lh);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hv[qq][e] = acc1[j][4 * q + e] + bv[e];
+        }
+        if (!(GCV_MLP_ABLATE & 1)) act4n<ACT_GELU, T, QB>(hv);
+#pragma unroll
+        for (int qq = 0; qq < QB; ++qq) {
+          const int q = q0 + qq;
+          typedef T t4 __attribute__((ext_vector_type(4)));
+          const t4 h4 = {from_f<T>(hv[qq][0]), from_f<T>(hv[qq][1]), from_f<T>(hv[qq][2]), from_f<T>(hv[qq][3])};
+          const uint2 pk = __builtin_bit_cast(uint2, h4);
+          hf[q >> 1][2 * (q & 1)] = pk.x;
+          hf[q >> 1][2 * (q & 1) + 1] = pk.y;
+        }
       }
       {
         // SB k-steps of this 32-hidden group per batch: SB*NO fragment reads, then SB*NO MFMAs

@@ -97,36 +97,74 @@ template <int ACT> __device__ __forceinline__ float act_fn(float x) {
 // over all x, i.e. 30x below the fp16 rounding step of the stored result; h(4.5) = 1.5e-5 is the tail that is cut).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 splat2(float c) { return (f32x2){c, c}; }
+// NCH independent Horner chains advance in lockstep: a dependent v_pk_fma_f32 needs wait states, so one chain at a
+// time leaves the packed pipe half idle (the compiler pads it with s_nop); 4 chains keep it issuing back to back.
+template <int NCH> __device__ __forceinline__ void gelu_pk_n(f32x2 (&x)[NCH]) {
+  constexpr float kC[11] = {2.749713404e-02f, -1.330395067e-01f, 2.465923971e-01f, -1.472158060e-01f,
+                            -2.029683018e-01f, 4.347813707e-01f, -2.049071560e-01f, -1.763150062e-01f,
+                            1.763803063e-01f, 2.178248281e-02f, -4.258673483e-02f};
+  f32x2 t[NCH], p[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const f32x2 a = {fminf(fabsf(x[c][0]), 4.5f), fminf(fabsf(x[c][1]), 4.5f)};
+    t[c] = __builtin_elementwise_fma(a, splat2(0.44444444444f), splat2(-1.0f));
+    p[c] = __builtin_elementwise_fma(splat2(kC[10]), t[c], splat2(kC[9]));
+  }
+#pragma unroll
+  for (int k = 8; k >= 0; --k) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) p[c] = __builtin_elementwise_fma(p[c], t[c], splat2(kC[k]));
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const f32x2 r = {fmaxf(x[c][0], 0.0f), fmaxf(x[c][1], 0.0f)};
+    x[c] = r - p[c];
+  }
+}
 __device__ __forceinline__ f32x2 gelu_pk(f32x2 x) {
-  const f32x2 a = {fminf(fabsf(x[0]), 4.5f), fminf(fabsf(x[1]), 4.5f)};
-  const f32x2 t = __builtin_elementwise_fma(a, splat2(0.44444444444f), splat2(-1.0f));
-  f32x2 p = splat2(-4.258673483e-02f);
-  p = __builtin_elementwise_fma(p, t, splat2(2.178248281e-02f));
-  p = __builtin_elementwise_fma(p, t, splat2(1.763803063e-01f));
-  p = __builtin_elementwise_fma(p, t, splat2(-1.763150062e-01f));
-  p = __builtin_elementwise_fma(p, t, splat2(-2.049071560e-01f));
-  p = __builtin_elementwise_fma(p, t, splat2(4.347813707e-01f));
-  p = __builtin_elementwise_fma(p, t, splat2(-2.029683018e-01f));
-  p = __builtin_elementwise_fma(p, t, splat2(-1.472158060e-01f));
-  p = __builtin_elementwise_fma(p, t, splat2(2.465923971e-01f));
-  p = __builtin_elementwise_fma(p, t, splat2(-1.330395067e-01f));
-  p = __builtin_elementwise_fma(p, t, splat2(2.749713404e-02f));
-  const f32x2 r = {fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f)};
-  return r - p;
+  f32x2 v[1] = {x};
+  gelu_pk_n<1>(v);
+  return v[0];
 }
 
-// v[e] = act(v[e] + b[e]) for four consecutive channels; 16-bit storage takes the packed GELU
-template <int ACT, typename T> __device__ __forceinline__ void bias_act4(float (&v)[4], const f32x4 b) {
+// activation of NG groups of four consecutive channels (bias already added); for 16-bit GELU the 2*NG packed
+// pairs are the independent chains of gelu_pk_n
+template <int ACT, typename T, int NG> __device__ __forceinline__ void act4n(float (&v)[NG][4]) {
 #ifndef GCV_GELU_EXACT
   if (ACT == ACT_GELU && sizeof(T) == 2) {
-    const f32x2 lo = gelu_pk((f32x2){v[0], v[1]} + (f32x2){b[0], b[1]});
-    const f32x2 hi = gelu_pk((f32x2){v[2], v[3]} + (f32x2){b[2], b[3]});
-    v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+    f32x2 x[2 * NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      x[2 * g] = (f32x2){v[g][0], v[g][1]};
+      x[2 * g + 1] = (f32x2){v[g][2], v[g][3]};
+    }
+    gelu_pk_n<2 * NG>(x);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      v[g][0] = x[2 * g][0]; v[g][1] = x[2 * g][1]; v[g][2] = x[2 * g + 1][0]; v[g][3] = x[2 * g + 1][1];
+    }
     return;
   }
 #endif
 #pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = act_fn<ACT>(v[e] + b[e]);
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[g][e] = act_fn<ACT>(v[g][e]);
+}
+// NG groups that share one bias vector (the MI token blocks of a wave)
+template <int ACT, typename T, int NG> __device__ __forceinline__ void bias_act4n(float (&v)[NG][4], const f32x4 b) {
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[g][e] += b[e];
+  act4n<ACT, T, NG>(v);
+}
+
+template <int ACT, typename T> __device__ __forceinline__ void bias_act4(float (&v)[4], const f32x4 b) {
+  float w[1][4] = {{v[0], v[1], v[2], v[3]}};
+  bias_act4n<ACT, T, 1>(w, b);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = w[0][e];
 }
 
 // staged-row length (dwords) of the epilogue tile: BN elements + a pad that makes the 32 token rows a

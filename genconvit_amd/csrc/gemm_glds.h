@@ -20,12 +20,36 @@
 
 namespace gcv {
 
-constexpr int kGldsBM = 128, kGldsBN = 192, kGldsBKB = 64, kGldsStages = 4;
+#ifndef GCV_GLDS_ABLATE
+#define GCV_GLDS_ABLATE 0     // diagnostics only: 1 = no MFMA/fragment reads, 2 = no steady-state loads, 4 = no epilogue math
+#endif
+#ifndef GCV_GLDS_STAGES
+#define GCV_GLDS_STAGES 4
+#endif
+#ifndef GCV_GLDS_STAMPS
+#define GCV_GLDS_STAMPS 0     // diagnostics only: per-workgroup s_memtime stamps + HW_ID into a side buffer
+#endif
+#if GCV_GLDS_STAMPS
+__device__ unsigned long long gcv_glds_stamps[4096 * 8];
+#define GLDS_STAMP(i)                                                                 \
+  do {                                                                                \
+    if (blockIdx.x < 4096 && threadIdx.x == 0) {                                      \
+      unsigned long long _t;                                                          \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");       \
+      gcv_glds_stamps[blockIdx.x * 8 + (i)] = _t;                                     \
+    }                                                                                 \
+  } while (0)
+#else
+#define GLDS_STAMP(i) do { } while (0)
+#endif
+constexpr int kGldsBM = 128, kGldsBN = 192, kGldsBKB = 64, kGldsStages = GCV_GLDS_STAGES;
 
 template <typename T> struct GldsSmem {
   static constexpr int kStage = (kGldsBM + kGldsBN) * kGldsBKB;            // 20480
   static constexpr int kMain = kGldsStages * kStage;                       // 81920
-  static constexpr int kEpi = kGldsBM * (kGldsBN / 2 + 2) * 4;             // 16-bit staging
+  static constexpr int kEpiRow = kGldsBN / 2 + 4;                          // dwords per staged row: 16-B aligned rows
+  static constexpr int kEpiBG = kGldsBM * kEpiRow * 4;                      // byte offset of the bias|gamma broadcast rows
+  static constexpr int kEpi = kEpiBG + 2 * kGldsBN * 4;
   static constexpr int bytes = kMain > kEpi ? kMain : kEpi;
 };
 
@@ -48,6 +72,12 @@ __global__ void __launch_bounds__(256, 2) gemm_glds_kernel(const GemmArgs g) {
   const int lr = lane & 31, lh = lane >> 5;
   const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 96;
 
+  GLDS_STAMP(0);
+#if GCV_GLDS_STAMPS
+  if (blockIdx.x < 4096 && threadIdx.x == 0)
+    gcv_glds_stamps[blockIdx.x * 8 + 5] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) |
+                                          ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
+#endif
   const int ntn = g.N / BN;
   const int ntm = (g.M + BM - 1) / BM;
   const int bid = xcd_remap(blockIdx.x, ntm * ntn);
@@ -115,6 +145,16 @@ __global__ void __launch_bounds__(256, 2) gemm_glds_kernel(const GemmArgs g) {
     }
   };
 
+  // bias / layer-scale for this tile's 192 channels: fetched now by 96 lanes (one f32x4 each) so the latency hides
+  // under the main loop; broadcast through LDS once the ring is free.  (Older than every DMA, so the counted
+  // vmcnt waits below are unaffected.)
+  f32x4 pre = {0.f, 0.f, 0.f, 0.f};
+  if (tid < BN / 4) {
+    if (g.bias) pre = *(const f32x4*)(g.bias + n0 + 4 * tid);
+  } else if (EPI == EPI_RESID && tid < BN / 2) {
+    pre = *(const f32x4*)(g.gamma + n0 + 4 * (tid - BN / 4));
+  }
+
   // ---- pipeline: stages kt+1 .. kt+S-2 stay in flight while stage kt is consumed ----
 #pragma unroll
   for (int s = 0; s < S - 1; ++s)
@@ -124,53 +164,83 @@ __global__ void __launch_bounds__(256, 2) gemm_glds_kernel(const GemmArgs g) {
     // my DMAs for stage kt have landed once at most (S-2) younger stages (QPW each) are outstanding
     // (one asm statement so no LDS access can be scheduled between the wait and the barrier)
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((S - 2) * QPW) : "memory");   // stage kt landed everywhere; all left kt-1
-    if (kt + S - 1 < nkt) issue(kt + S - 1); // refill the buffer stage kt-1 used
-    compute(kt);
+    if (kt == 0) GLDS_STAMP(1);
+    if (!(GCV_GLDS_ABLATE & 2) && kt + S - 1 < nkt) issue(kt + S - 1); // refill the buffer stage kt-1 used
+    if (!(GCV_GLDS_ABLATE & 1)) compute(kt);
   }
   for (int kt = n_steady; kt < nkt; ++kt) {  // drain: fewer stages outstanding, wait for all of them
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    compute(kt);
+    if (!(GCV_GLDS_ABLATE & 1)) compute(kt);
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all waves done reading the ring before it is reused
+  GLDS_STAMP(2);
 
   // ---- epilogue: token on the lane, 4 consecutive channels in 4 consecutive registers ----
-  constexpr int SROW = BN / 2 + 2;           // dwords per staged row (16-bit), 2*odd -> conflict-free b64 writes
+  // Every global read the epilogue needs is in flight at once (the residual: 24 independent 8-byte loads per lane,
+  // issued before the barrier) or already in registers (bias / gamma), so it pays ONE memory latency, not one
+  // per 4-channel group.
+  constexpr int SROW = GldsSmem<T>::kEpiRow;
   typedef T t4 __attribute__((ext_vector_type(4)));
   uint32_t* sC = reinterpret_cast<uint32_t*>(smem);
+  float* sBG = reinterpret_cast<float*>(smem + GldsSmem<T>::kEpiBG);
   T* Cp = (T*)g.C;
+  t4 rres[EPI == EPI_RESID ? MI : 1][EPI == EPI_RESID ? NI : 1][4];
+  if (EPI == EPI_RESID && !(GCV_GLDS_ABLATE & 4)) {
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int ml = wm0 + i * 32 + lr;
-    const int m = m0 + ml;
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm0 + i * 32 + lr;
+      const int64_t mm = m < g.M ? m : g.M - 1;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
+      for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int nl = wn0 + j * 32 + 8 * q + 4 * lh;
-        const int n = n0 + nl;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (g.bias) bv = *(const f32x4*)(g.bias + n);
-        float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        bias_act4<ACT, T>(v, bv);
-        if (EPI == EPI_RESID) {
-          const f32x4 gv = *(const f32x4*)(g.gamma + n);
-          const int64_t mm = m < g.M ? m : g.M - 1;
-          const t4 r = *(const t4*)((const T*)g.resid + mm * g.ldc + n);
+        for (int q = 0; q < 4; ++q)
+          rres[i][j][q] = *(const t4*)((const T*)g.resid + mm * g.ldc + n0 + wn0 + j * 32 + 8 * q + 4 * lh);
+    }
+  }
+  if (tid < BN / 2) *(f32x4*)(sBG + 4 * tid) = pre;
+  __syncthreads();
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], gv[e], to_f(r[e]));
+  for (int j = 0; j < NI; ++j) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int nl = wn0 + j * 32 + 8 * q + 4 * lh;
+      const f32x4 bv = *(const f32x4*)(sBG + nl);
+      f32x4 gv = {1.f, 1.f, 1.f, 1.f};
+      if (EPI == EPI_RESID) gv = *(const f32x4*)(sBG + BN + nl);
+      float v[MI][4];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[i][e] = acc[i][j][4 * q + e];
+      if (!(GCV_GLDS_ABLATE & 4)) bias_act4n<ACT, T, MI>(v, bv);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int ml = wm0 + i * 32 + lr;
+        if (EPI == EPI_RESID && !(GCV_GLDS_ABLATE & 4)) {
+          const t4 r = rres[i][j][q];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[i][e] = fmaf(v[i][e], gv[e], to_f(r[e]));
         }
-        t4 o = {from_f<T>(v[0]), from_f<T>(v[1]), from_f<T>(v[2]), from_f<T>(v[3])};
+        t4 o = {from_f<T>(v[i][0]), from_f<T>(v[i][1]), from_f<T>(v[i][2]), from_f<T>(v[i][3])};
         *(t4*)(sC + ml * SROW + (nl >> 1)) = o;
       }
     }
   }
+  GLDS_STAMP(3);
   __syncthreads();
-  constexpr int PPR = BN / 4;
+  // coalesced write-out: 16 bytes per lane, 24 lanes per 384-byte tile row
+  constexpr int PPR = BN / 8;
+#pragma unroll 4
   for (int idx = tid; idx < BM * PPR; idx += 256) {
     const int rl = idx / PPR, pc = idx - rl * PPR;
     const int m = m0 + rl;
-    if (m < g.M) *(t4*)(Cp + (int64_t)m * g.ldc + n0 + 4 * pc) = *(const t4*)(sC + rl * SROW + 2 * pc);
+    if (m < g.M) *(u32x4*)(Cp + (int64_t)m * g.ldc + n0 + 8 * pc) = *(const u32x4*)(sC + rl * SROW + 4 * pc);
   }
+  GLDS_STAMP(4);      // stores issued
+#if GCV_GLDS_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GLDS_STAMP(6);      // stores acknowledged
+#endif
 }
 
 template <typename T> int launch_gemm_glds(const GemmArgs& g, int epi, hipStream_t s);

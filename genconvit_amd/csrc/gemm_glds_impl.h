@@ -25,9 +25,9 @@ template <typename T> bool gemm_glds_applicable(const GemmArgs& g, int a_mode, i
   if (disabled || sizeof(T) != 2 || a_mode != A_PLAIN) return false;
   if (!(epi == EPI_BIAS_ACT && (g.act == ACT_NONE || g.act == ACT_GELU)) && !(epi == EPI_RESID && g.act == ACT_NONE))
     return false;
-  if (g.N % kGldsBN != 0 || g.K % 32 != 0 || g.M < 256 || g.lda % 8 != 0 || g.ldc % 4 != 0) return false;
+  if (g.N % kGldsBN != 0 || g.K % 32 != 0 || g.M < 256 || g.lda % 8 != 0 || g.ldc % 8 != 0) return false;
   auto al = [](const void* p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; };
-  if (!al(g.A, 16) || !al(g.Wt, 16) || !al(g.C, 8) || (g.bias && !al(g.bias, 16))) return false;
+  if (!al(g.A, 16) || !al(g.Wt, 16) || !al(g.C, 16) || (g.bias && !al(g.bias, 16))) return false;
   if (epi == EPI_RESID && (!g.gamma || !g.resid || !al(g.gamma, 16) || !al(g.resid, 8))) return false;
   return true;
 }
