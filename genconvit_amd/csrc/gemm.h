@@ -174,7 +174,8 @@ template <int BN, bool F32> struct StageRow { static constexpr int dwords = F32 
 template <typename T, int BM, int BN, int BKB, int EPI> struct GemmSmem {
   static constexpr bool kStageF32 = (sizeof(T) == 4) || EPI == EPI_RESID || EPI == EPI_SPLITK;
   static constexpr int kMain = 2 * (BM + BN) * BKB;
-  static constexpr int kEpi = BM * StageRow<BN, kStageF32>::dwords * 4;
+  static constexpr int kEpiBG = BM * StageRow<BN, kStageF32>::dwords * 4;     // bias | gamma broadcast rows live here
+  static constexpr int kEpi = kEpiBG + 2 * BN * 4;
   static constexpr int bytes = kMain > kEpi ? kMain : kEpi;
 };
 
@@ -260,6 +261,21 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   }
 
   u32x4 areg[A_SLOTS], breg[B_SLOTS];
+
+  // bias / layer-scale of this tile's BN channels: one f32x4 per lane of the first BN/2 lanes, fetched now so the
+  // latency hides under the main loop; broadcast through LDS in the epilogue (a per-group global load there is a
+  // dependent ~1 us latency, 4*NI*MI of them per tile)
+  f32x4 pre = {0.f, 0.f, 0.f, 0.f};
+  if (EPI != EPI_SPLITK) {
+    if (tid < BN / 4) {
+      const int n = n0 + 4 * tid;
+      const int bi = (EPI == EPI_CONVT) ? (n & ((1 << g.cout_log2) - 1)) : n;
+      if (g.bias && n < g.N) pre = *(const f32x4*)(g.bias + bi);
+    } else if (EPI == EPI_RESID && tid < BN / 2) {
+      const int n = n0 + 4 * (tid - BN / 4);
+      if (n < g.N) pre = *(const f32x4*)(g.gamma + n);
+    }
+  }
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
   auto fetch = [&](int kt) {
@@ -370,37 +386,41 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmArgs g) {
   constexpr bool STAGE_F32 = GemmSmem<T, BM, BN, BKB, EPI>::kStageF32;
   constexpr int SROW = StageRow<BN, STAGE_F32>::dwords;       // dwords per staged row
   uint32_t* sC = reinterpret_cast<uint32_t*>(smem);
+  float* sBG = reinterpret_cast<float*>(smem + GemmSmem<T, BM, BN, BKB, EPI>::kEpiBG);
+  if (EPI != EPI_SPLITK) {
+    if (tid < BN / 2) *(f32x4*)(sBG + 4 * tid) = pre;
+    __syncthreads();
+  }
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int ml = wm0 + i * 32 + lr;
+  for (int j = 0; j < NI; ++j) {
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
+    for (int q = 0; q < 4; ++q) {
+      const int nl = wn0 + j * 32 + 8 * q + 4 * lh;
+      float v[MI][4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int nl = wn0 + j * 32 + 8 * q + 4 * lh;
-        const int n = n0 + nl;
-        float v[4];
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-        if (EPI != EPI_SPLITK) {
-          f32x4 bv = {0.f, 0.f, 0.f, 0.f}, gv = {1.f, 1.f, 1.f, 1.f};
-          if (n < g.N) {
-            const int bi = (EPI == EPI_CONVT) ? (n & ((1 << g.cout_log2) - 1)) : n;
-            if (g.bias) bv = *(const f32x4*)(g.bias + bi);
-            if (EPI == EPI_RESID) gv = *(const f32x4*)(g.gamma + n);
-          }
-          bias_act4<ACT, T>(v, bv);
-          if (EPI == EPI_RESID) {
+        for (int e = 0; e < 4; ++e) v[i][e] = acc[i][j][4 * q + e];
+      if (EPI != EPI_SPLITK) {
+        const f32x4 bv = *(const f32x4*)(sBG + nl);
+        bias_act4n<ACT, T, MI>(v, bv);
+        if (EPI == EPI_RESID) {
+          const f32x4 gv = *(const f32x4*)(sBG + BN + nl);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= gv[e];
-          }
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] *= gv[e];
         }
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int ml = wm0 + i * 32 + lr;
         if (STAGE_F32) {
-          f32x4 o = {v[0], v[1], v[2], v[3]};
+          f32x4 o = {v[i][0], v[i][1], v[i][2], v[i][3]};
           *(f32x4*)(sC + ml * SROW + nl) = o;
         } else {
           typedef T t4 __attribute__((ext_vector_type(4)));
-          t4 o = {from_f<T>(v[0]), from_f<T>(v[1]), from_f<T>(v[2]), from_f<T>(v[3])};
+          t4 o = {from_f<T>(v[i][0]), from_f<T>(v[i][1]), from_f<T>(v[i][2]), from_f<T>(v[i][3])};
           *(t4*)(sC + ml * SROW + (nl >> 1)) = o;
         }
       }
