@@ -641,6 +641,150 @@ dwconv7_ln_v3_kernel(const T* __restrict__ x, const float* __restrict__ wdw, con
   }
 }
 
+// ------------------------------------------------------------------ K4 v4 (16-bit, C = 96): v3 + tile pipelining
+// One workgroup walks TPW consecutive 7x7 tiles (a tile row of the image).  The halo window of tile t+1 is fetched
+// into registers (4 x 16 B per thread) right after tile t's window has been handed to LDS, so the global / L2 latency
+// of the halo (the largest single wait of v3: ~3 us of a ~10 us tile) runs under the taps, LayerNorm and store of
+// tile t.  Taps are packed into LDS once per workgroup instead of once per tile.  __launch_bounds__(.., 6) keeps the
+// kernel at <= 80 VGPRs so two 11-wave workgroups still share a CU.
+template <typename T, int C, int TPW>
+__global__ void __launch_bounds__(7 * C, 6)
+dwconv7_ln_v4_kernel(const T* __restrict__ x, const float* __restrict__ wdw, const float* __restrict__ bdw,
+                     const float* __restrict__ lnw, const float* __restrict__ lnb, T* __restrict__ y, int nimg, int H,
+                     int W, float eps) {
+  static_assert(sizeof(T) == 2 && C == 96, "v4 covers 16-bit storage, C = 96");
+  constexpr int NT = 7 * C;
+  constexpr int CP = C / 8;                           // 16-byte pieces per pixel
+  constexpr int IN_BYTES = 169 * C * 2;
+  constexpr int STAT_OFF = 49 * C * 4;
+  constexpr int OUT_OFF = (STAT_OFF + 49 * 8 + 255) & ~255;
+  static_assert(OUT_OFF + 49 * C * 2 <= IN_BYTES, "LN / output staging must fit in the halo window");
+  extern __shared__ __attribute__((aligned(16))) unsigned char dw4_lds[];
+  unsigned short* sIn = reinterpret_cast<unsigned short*>(dw4_lds);
+  float* sval = reinterpret_cast<float*>(dw4_lds);
+  float* stats = reinterpret_cast<float*>(dw4_lds + STAT_OFF);
+  unsigned short* sOut = reinterpret_cast<unsigned short*>(dw4_lds + OUT_OFF);
+  uint32_t* sW2 = reinterpret_cast<uint32_t*>(dw4_lds + IN_BYTES);     // [28][C] packed tap pairs
+
+  const int tid = threadIdx.x;
+  const int tiles_x = (W + 6) / 7, tiles_y = (H + 6) / 7;
+  const int ntiles = nimg * tiles_x * tiles_y;
+  const int tile0 = xcd_remap(blockIdx.x, gridDim.x) * TPW;
+
+  for (int i = tid; i < 28 * C; i += NT) {
+    const int c = i % C, kj = i / C;
+    const int ky = kj >> 2, j = kj & 3;
+    const uint32_t lo = bits16<T>(wdw[(ky * 7 + 2 * j) * C + c]);
+    const uint32_t hi = (j < 3) ? bits16<T>(wdw[(ky * 7 + 2 * j + 1) * C + c]) : 0u;
+    sW2[i] = lo | (hi << 16);
+  }
+  const int rg = tid / C, c = tid - rg * C;             // output row of the tile, channel
+  const float bv = bdw[c], lw = lnw[c], lb = lnb[c];
+
+  constexpr int NPIECE = 169 * CP;
+  constexpr int NIT = (NPIECE + NT - 1) / NT;
+  u32x4 v[NIT];
+  auto fetch = [&](int tile) {
+    const int tx = tile % tiles_x, t2 = tile / tiles_x;
+    const int ty = t2 % tiles_y, b = t2 / tiles_y;
+    const int x0 = tx * 7, y0 = ty * 7;
+    const int64_t img = (int64_t)b * H * W;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int idx = tid + i * NT;
+      const int pix = idx / CP, pc = idx - pix * CP;
+      const int r = pix / 13, sx = pix - r * 13;
+      const int iy = y0 + r - 3, ix = x0 + sx - 3;
+      const bool ok = idx < NPIECE && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const int64_t off = ok ? ((img + (int64_t)iy * W + ix) * C + 8 * pc) : 0;
+      const u32x4 t = *(const u32x4*)(x + off);
+      const uint32_t m = ok ? 0xffffffffu : 0u;
+      v[i] = u32x4{t[0] & m, t[1] & m, t[2] & m, t[3] & m};
+    }
+  };
+  if (tile0 < ntiles) fetch(tile0);
+
+#pragma unroll 1
+  for (int t = 0; t < TPW; ++t) {
+    const int tile = tile0 + t;
+    if (tile >= ntiles) break;                         // uniform over the workgroup
+    const int tx = tile % tiles_x, t2 = tile / tiles_x;
+    const int ty = t2 % tiles_y, b = t2 / tiles_y;
+    const int x0 = tx * 7, y0 = ty * 7;
+    const int64_t img = (int64_t)b * H * W;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int idx = tid + i * NT;
+      if (idx < NPIECE) *(u32x4*)(sIn + idx * 8) = v[i];
+    }
+    __syncthreads();
+    if (t + 1 < TPW && tile + 1 < ntiles) fetch(tile + 1);   // in flight until the next iteration's LDS write
+
+    float acc[7];
+#pragma unroll
+    for (int ox = 0; ox < 7; ++ox) acc[ox] = bv;
+    {
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) {
+        __builtin_amdgcn_sched_barrier(0);               // one kernel row at a time: bounds the LDS reads in flight (VGPRs)
+        const int r = rg + ky;
+        uint32_t w2[4];                                  // this kernel row's tap pairs (kept out of the loop-carried set)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w2[j] = sW2[(ky * 4 + j) * C + c];
+        uint32_t raw[14];
+#pragma unroll
+        for (int s = 0; s < 13; ++s) raw[s] = sIn[(r * 13 + s) * C + c];
+        raw[13] = 0u;
+        uint32_t pp[13];
+#pragma unroll
+        for (int s = 0; s < 13; ++s) pp[s] = raw[s] | (raw[s + 1] << 16);
+#pragma unroll
+        for (int ox = 0; ox < 7; ++ox)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[ox] = Dot2<T>::run(pp[ox + 2 * j], w2[j], acc[ox]);
+      }
+    }
+    __syncthreads();                                     // halo window is free: reuse it for LayerNorm
+#pragma unroll
+    for (int ox = 0; ox < 7; ++ox) sval[(rg * 7 + ox) * C + c] = acc[ox];
+    __syncthreads();
+    {
+      const int grp = tid >> 5, gl = tid & 31;
+      for (int p = grp; p < 49; p += NT / 32) {
+        const float* row = sval + p * C;
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < C / 32; ++k) s += row[gl + 32 * k];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s * (1.0f / C);
+        float q = 0.0f;
+#pragma unroll
+        for (int k = 0; k < C / 32; ++k) { const float d = row[gl + 32 * k] - mean; q = fmaf(d, d, q); }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        if (gl == 0) {
+          stats[2 * p] = mean;
+          stats[2 * p + 1] = 1.0f / sqrtf(q * (1.0f / C) + eps);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ox = 0; ox < 7; ++ox) {
+      const int p = rg * 7 + ox;
+      sOut[p * C + c] = (unsigned short)bits16<T>((acc[ox] - stats[2 * p]) * stats[2 * p + 1] * lw + lb);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 49 * CP; idx += NT) {
+      const int p = idx / CP, pc = idx - p * CP;
+      const int oy = y0 + p / 7, ox = x0 + p % 7;
+      if (oy < H && ox < W) *(u32x4*)(y + ((img + (int64_t)oy * W + ox) * C + 8 * pc)) = *(const u32x4*)(sOut + p * C + 8 * pc);
+    }
+    __syncthreads();                                     // staging is read out: the next halo may overwrite it
+  }
+}
+
 // ------------------------------------------------------------------ K6: LN2d + space-to-depth
 // x (nimg,H,W,C) -> out (nimg,H/2,W/2,4C), K index (dy*2+dx)*C + c; floor(H/2): an odd last
 // row/col is dropped exactly as Conv2d(k=2,s=2) drops it (7 -> 3 in the 112-px pass).

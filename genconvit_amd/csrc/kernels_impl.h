@@ -75,7 +75,18 @@ static int launch_dw_v3(const T* x, const float* wdw, const float* bdw, const fl
   return 0;
 }
 
-// 0: v3 + dot2 (default for 16-bit C<=192), 4: v3 with fp32 FMA taps, 1: v2 + dot2, 2: v1 everywhere,
+template <typename T, int C, int TPW>
+static int launch_dw_v4(const T* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb, T* y,
+                        int nimg, int H, int W, float eps, hipStream_t s) {
+  constexpr int LDS = 169 * C * 2 + 28 * C * 4;
+  const int tiles = nimg * cdiv(H, 7) * cdiv(W, 7);
+  hipLaunchKernelGGL((dwconv7_ln_v4_kernel<T, C, TPW>), dim3(cdiv(tiles, TPW)), dim3(7 * C), LDS, s, x, wdw, bdw, lnw, lnb,
+                     y, nimg, H, W, eps);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// 5: v4 (tile-pipelined v3, C = 96), 0: v3 + dot2 (default for 16-bit C<=192), 4: v3 with fp32 FMA taps, 1: v2 + dot2, 2: v1 everywhere,
 // 3: v2 with fp32 FMA taps (env GCV_DWCONV_MODE, A/B switch for profiling)
 static inline int dwconv_mode() {
   static const int mode = [] { const char* e = std::getenv("GCV_DWCONV_MODE"); return e ? std::atoi(e) : 0; }();
@@ -90,6 +101,8 @@ int launch_dwconv7_ln(const T* x, const float* wdw, const float* bdw, const floa
     const int mode = dwconv_mode();
     if (mode != 2 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0) {
       if (C == 96) {
+        if (mode == 5) return launch_dw_v4<T, 96, 8>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
+        if (mode == 6) return launch_dw_v4<T, 96, 4>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
         if (mode == 0) return launch_dw_v3<T, 96, 1, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
         if (mode == 4) return launch_dw_v3<T, 96, 1, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
         return mode == 1 ? launch_dw_v2<T, 96, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s)
