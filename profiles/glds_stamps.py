@@ -21,10 +21,13 @@ for _ in range(3):
     _lib.check(lib.gcv_k_gemm(_lib.GCV_F16, _lib.A_PLAIN, epi, ctypes.byref(g), _lib.current_stream_ptr(dev)), "gemm")
 torch.cuda.synchronize()
 ntiles = min(4096, ((M + 127) // 128) * (N // 192))
+if os.environ.get('GLDS2'):
+    ntiles = 256          # persistent kernel: one row per workgroup (stamps of its third tile)
 buf = (ctypes.c_ulonglong * (4096 * 8))()
 raw = ctypes.CDLL(_lib.LIB_PATH)
 assert raw.gcv_debug_read_glds_stamps(buf, 4096 * 8) == 0
 rows = [[buf[b * 8 + i] for i in range(8)] for b in range(ntiles)]
+rows = [r for r in rows if r[0] and r[6]]
 names = ["start", "first stage landed", "mainloop done", "epilogue math+LDS stage done", "stores issued", None, "stores acked"]
 prev = 0
 for i in (1, 2, 3, 4, 6):
@@ -50,7 +53,7 @@ avg = collections.Counter()
 for c in conc:
     for k, v in c.items():
         avg[k] += v / len(conc)
-print("time share by number of co-resident workgroups per CU:", {k: round(v, 3) for k, v in sorted(avg.items())})
+print("time share by number of co-resident workgroups per CU:", {k: round(v, 3) for k, v in sorted(avg.items()) if 0 <= k <= 8})
 key0 = sorted(percu)[0]
 print("timeline of CU", key0)
 t0 = min(s for s, e, b in percu[key0])

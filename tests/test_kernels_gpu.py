@@ -443,6 +443,33 @@ def test_gemm_lds_dma_pipeline_residual(dt, M, N, K):
     assert_close(Xd, X + gamma * (A @ W.t() + bias), tol(dtype, 2.0), "glds gemm resid")
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K,act", [(8229, 1536, 384, "gelu"), (12544, 3072, 768, "gelu"), (16400, 768, 128, "none")])
+def test_gemm_lds_dma_many_tiles_bias_act(dt, M, N, K, act):
+    """Several waves of tiles per CU (the B=128 shapes of stages 2/3); M has a ragged last tile."""
+    dtype = DTYPES[dt]
+    act = {"none": _lib.ACT_NONE, "gelu": _lib.ACT_GELU}[act]
+    A, W = q(rnd((M, K), 1), dtype), q(rnd((N, K), 2, 1 / math.sqrt(K)), dtype)
+    bias = rnd((N,), 3, 0.1)
+    C = torch.full((M + 8, N), 7.0, dtype=dtype, device=dev())
+    gemm(dtype, _lib.A_PLAIN, _lib.EPI_BIAS_ACT, D(A, dtype), D(W, dtype), C, M, N, K, lda=K, ldc=N, bias=D(bias), act=act)
+    assert_close(C[:M], act_ref(A @ W.t() + bias, act), tol(dtype, 2.0), "glds gemm (many tiles)")
+    assert (C[M:].float() == 7.0).all(), "rows past M must not be written"
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K", [(32868, 384, 1536), (16500, 768, 3072)])
+def test_gemm_lds_dma_many_tiles_residual(dt, M, N, K):
+    dtype = DTYPES[dt]
+    A, W = q(rnd((M, K), 1), dtype), q(rnd((N, K), 2, 1 / math.sqrt(K)), dtype)
+    bias, gamma = rnd((N,), 3, 0.1), rnd((N,), 4, 0.5)
+    X = q(rnd((M, N), 5), dtype)
+    Xd = D(X, dtype).clone()
+    gemm(dtype, _lib.A_PLAIN, _lib.EPI_RESID, D(A, dtype), D(W, dtype), Xd, M, N, K, lda=K, ldc=N, bias=D(bias),
+         gamma=D(gamma), resid=Xd)
+    assert_close(Xd, X + gamma * (A @ W.t() + bias), tol(dtype, 2.0), "glds gemm resid (many tiles)")
+
+
 def test_preprocess_frame_on_device_matches_reference_semantics():
     """Row N1: uint8 NHWC -> normalised NCHW (model/pred_func.py:95-108, dataset/loader.py:63-65,77)."""
     from genconvit_amd import synth
