@@ -1,6 +1,9 @@
 // launcher + weight packer for fused_mlp_kernel (included by fused_mlp_{f16,bf16}.hip)
 #pragma once
+#include <cstdlib>
+
 #include "fused_mlp.h"
+#include "fused_mlp_res.h"
 
 namespace gcv {
 
@@ -41,10 +44,27 @@ template <typename T, int C, int NW> static int launch_mlp_c(const MlpArgs& a, h
   return 0;
 }
 
+template <typename T> int launch_fused_mlp_res(const MlpArgs& a, hipStream_t s) {
+  constexpr int SMEM = MlpResSmem::bytes;
+  static bool attr_done = false;
+  if (!attr_done) {
+    GCV_CHECK_HIP(hipFuncSetAttribute((const void*)fused_mlp_res_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_done = true;
+  }
+  const int wave_tiles = cdiv(a.M, 32);
+  const int nwg = cdiv(wave_tiles, 8) < 256 ? cdiv(wave_tiles, 8) : 256;    // one persistent workgroup per CU
+  hipLaunchKernelGGL((fused_mlp_res_kernel<T>), dim3(nwg), dim3(512), SMEM, s, a);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 template <typename T> int launch_fused_mlp(const MlpArgs& a, int C, hipStream_t s) {
   GCV_REQUIRE(a.M > 0 && a.X && a.W1 && a.W2c && a.b1 && a.b2 && a.gamma && a.resid && a.out, "fused MLP: null argument");
   // C=96: 4-wave workgroups (81 KB LDS -> two independent workgroups per CU overlap each other's
   // prologue / epilogue); C=192: the double-buffered chunks fill the LDS, one 8-wave workgroup per CU
+  // C=96 with enough tokens to give every wave of the chip several tiles: weights resident in LDS, no barriers
+  static const int res_mode = [] { const char* e = std::getenv("GCV_MLP_RESIDENT"); return e ? std::atoi(e) : 1; }();
+  if (C == 96 && res_mode && a.M >= 256 * 8 * 32) return launch_fused_mlp_res<T>(a, s);
   if (C == 96) return launch_mlp_c<T, 96, 4>(a, s);
   if (C == 192) return launch_mlp_c<T, 192, 8>(a, s);
   set_error("fused MLP is built for C = 96 and C = 192");

@@ -1,0 +1,211 @@
+// Fused ConvNeXt MLP, C = 96, weights RESIDENT in LDS (16-bit storage):
+//     out = resid + gamma * ( W2 . GELU( W1 . x_ln + b1 ) + b2 )
+//
+// Why a second kernel for the first stage: at C = 96 the MLP is bound by the GELU, not by the MFMAs (per 32-token
+// wave tile: 144 MFMAs = 4.6k matrix cycles against ~2.9k VALU instructions = 11.5k issue cycles), so the only
+// way to finish sooner is to keep the vector pipe issuing all the time.  fused_mlp_kernel streams the weights
+// through LDS in chunks, which costs a workgroup barrier per chunk; the barrier puts every wave of the CU in the
+// same phase (all in GEMM1, then all in GELU, then all in GEMM2), so matrix and vector work never overlap.
+// Here both weight matrices (2 x 73.7 KB as 16-bit) live in LDS for the whole kernel:
+//   * one persistent 8-wave workgroup per CU loads W1 / W2 / b1 / b2 / gamma once (150 KB of the 160 KB LDS) and then
+//     never synchronises again: each wave walks its own 32-token tiles, so the two waves of a SIMD drift apart and one
+//     wave's GELU issues under the other's MFMAs
+//   * inside a wave the work is software-pipelined over 32-wide hidden groups g: GEMM1(g+1) and GEMM2(g-1) (12
+//     independent MFMAs) are issued around GELU(g), so its own vector instructions also have matrix work to hide under
+//   * rows are 192 B (no room for padding): the 16-byte chunk index is XOR-swizzled inside groups of four by
+//     (row >> 2) & 3, which puts the 16 lanes of a ds_read_b128 group on 16 distinct 16-byte bank groups
+//   * no LDS is left for an epilogue transposition: the (token on lane, 4 channels in registers) accumulator is
+//     stored as 8-byte pieces, 32 rows x 16 B per instruction; L2 merges the 12 pieces of a row before write-back
+#pragma once
+#include "fused_mlp.h"
+
+namespace gcv {
+
+struct MlpResSmem {
+  static constexpr int kRow = 192;                       // bytes per row of either weight image (96 x 16-bit)
+  static constexpr int kW1 = 0;                          // [384 hidden][96 k]
+  static constexpr int kW2 = 384 * kRow;                 // [4 chunks][96 out][96 hidden (permuted)]
+  static constexpr int kB1 = 2 * 384 * kRow;             // 384 floats
+  static constexpr int kB2 = kB1 + 384 * 4;              // 96 floats
+  static constexpr int kG = kB2 + 96 * 4;                // 96 floats
+  static constexpr int bytes = kG + 96 * 4;              // 149760
+};
+
+__device__ __forceinline__ int mlp_res_swz(int row, int k16) { return (k16 & ~3) | ((k16 & 3) ^ ((row >> 2) & 3)); }
+
+template <typename T>
+__global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) {
+  static_assert(sizeof(T) == 2, "fused MLP is built for 16-bit storage");
+  constexpr int C = 96, HC = 96, NG = 12;                 // 12 hidden groups of 32
+  constexpr int KP1 = C / 16;                             // 6 k-steps of GEMM1
+  constexpr int NO = C / 32;                              // 3 output-channel tiles
+  constexpr int ROW = MlpResSmem::kRow;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned char* sW1 = smem + MlpResSmem::kW1;
+  const unsigned char* sW2 = smem + MlpResSmem::kW2;
+  const float* sB1 = reinterpret_cast<const float*>(smem + MlpResSmem::kB1);
+  const float* sB2 = reinterpret_cast<const float*>(smem + MlpResSmem::kB2);
+  const float* sG = reinterpret_cast<const float*>(smem + MlpResSmem::kG);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  // ---- weights -> LDS, once ----
+  {
+    const unsigned char* g1 = (const unsigned char*)a.W1;
+    const unsigned char* g2 = (const unsigned char*)a.W2c;
+    for (int idx = tid; idx < 2 * 384 * 12; idx += 512) {
+      const int which = idx >= 384 * 12;
+      const int k2 = which ? idx - 384 * 12 : idx;
+      const int row = k2 / 12, k16 = k2 - row * 12;
+      const u32x4 v = *(const u32x4*)((which ? g2 : g1) + (int64_t)k2 * 16);
+      *(u32x4*)(smem + (which ? MlpResSmem::kW2 : MlpResSmem::kW1) + row * ROW + mlp_res_swz(row, k16) * 16) = v;
+    }
+    float* sf = reinterpret_cast<float*>(smem + MlpResSmem::kB1);
+    for (int i = tid; i < 384 + 96 + 96; i += 512)
+      sf[i] = i < 384 ? a.b1[i] : (i < 480 ? a.b2[i - 384] : a.gamma[i - 480]);
+  }
+  __syncthreads();
+
+  const T* __restrict__ Xp = (const T*)a.X;
+  const T* Rp = (const T*)a.resid;
+  T* Op = (T*)a.out;
+  typedef T t4 __attribute__((ext_vector_type(4)));
+
+  const int ntiles = (a.M + 31) / 32;
+  const int stride = (int)gridDim.x * 8;
+  // lane-constant parts of the fragment addresses: row r = 32*blk + lr has swizzle key (lr >> 2) & 3 (32*blk adds 0 mod 4
+  // to r >> 2 ... only when blk*8 is a multiple of 4, which it is)
+  const int key = (lr >> 2) & 3;
+  const int rowoff = lr * ROW;
+
+  for (int tile = (int)blockIdx.x * 8 + wave; tile < ntiles; tile += stride) {
+    const int64_t m = (int64_t)tile * 32 + lr;
+    const int64_t mc = m < a.M ? m : (int64_t)a.M - 1;        // clamp: tail rows compute garbage, store nothing
+    const int64_t mld = (GCV_MLP_ABLATE & 8) ? (int64_t)lr : mc;
+
+    u32x4 xf[KP1];                                             // x_ln fragments: k-step p, lane (token lr, half lh)
+#pragma unroll
+    for (int p = 0; p < KP1; ++p) xf[p] = *(const u32x4*)(Xp + mld * C + 16 * p + 8 * lh);
+
+    f32x16 acc2[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[o][r] = 0.0f;
+
+    // One pipeline step per 32-wide hidden group g, written as three fenced phases so that LDS latency is paid once
+    // per group and not once per MFMA (left alone, hipcc emits ds_read -> s_waitcnt -> v_mfma chains):
+    //   reads : b1(g) (4), W1 fragments of group g+1 (6), W2 fragments of group g (6)      -> 16 ds_read_b128 in flight
+    //   VALU  : h(g) = GELU(acc1(g) + b1(g)) packed to two 16-byte B fragments               (fragments land meanwhile)
+    //   MFMA  : acc1(g+1) = W1[g+1] . x  (6),  acc2 += W2[:, g] . h(g)  (6)                 (runs under the other wave's GELU)
+    auto frag_off = [&](int k16) { return ((k16 & ~3) | ((k16 & 3) ^ key)) << 4; };
+    auto read_w1 = [&](int g, u32x4 (&wf)[KP1]) {
+      const unsigned char* base = sW1 + g * 32 * ROW + rowoff;
+#pragma unroll
+      for (int p = 0; p < KP1; ++p) wf[p] = *(const u32x4*)(base + frag_off(2 * p + lh));
+    };
+    auto read_w2 = [&](int g, u32x4 (&w2f)[2][NO]) {
+      const int ch = g / 3, j = g - 3 * ch;
+      const unsigned char* base = sW2 + ch * HC * ROW + rowoff;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int o = 0; o < NO; ++o) w2f[s][o] = *(const u32x4*)(base + 32 * o * ROW + frag_off(2 * (2 * j + s) + lh));
+    };
+    auto read_b1 = [&](int g, f32x4 (&bv)[4]) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[q] = *(const f32x4*)(sB1 + g * 32 + 8 * q + 4 * lh);
+    };
+    auto mfma1 = [&](const u32x4 (&wf)[KP1], f32x16& acc1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[r] = 0.0f;
+#pragma unroll
+      for (int p = 0; p < KP1; ++p) Mfma<T>::run(wf[p], xf[p], acc1);
+    };
+    auto mfma2 = [&](const u32x4 (&w2f)[2][NO], const u32x4 (&hf)[2]) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int o = 0; o < NO; ++o) Mfma<T>::run(w2f[s][o], hf[s], acc2[o]);
+    };
+    auto gelu = [&](const f32x16& acc1, const f32x4 (&bv)[4], u32x4 (&hf)[2]) {
+#pragma unroll
+      for (int q0 = 0; q0 < 4; q0 += 2) {
+        float hv[2][4];
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hv[qq][e] = acc1[4 * (q0 + qq) + e] + bv[q0 + qq][e];
+        if (!(GCV_MLP_ABLATE & 1)) act4n<ACT_GELU, T, 2>(hv);
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const t4 h4 = {from_f<T>(hv[qq][0]), from_f<T>(hv[qq][1]), from_f<T>(hv[qq][2]), from_f<T>(hv[qq][3])};
+          const uint2 pk = __builtin_bit_cast(uint2, h4);
+          hf[q0 >> 1][2 * qq] = pk.x;
+          hf[q0 >> 1][2 * qq + 1] = pk.y;
+        }
+      }
+    };
+
+    // Steady state of one step (group g; C / N are the ping-pong GEMM1 accumulators):
+    //     h = GELU(C + b1(g))  ->  N = W1[g+1] . x ,  acc2 += W2[:, g] . h  ->  issue the LDS reads of step g+1
+    // The reads are issued right after the MFMAs that consumed the previous fragments, so their latency runs under
+    // those MFMAs; the next GELU waits on whichever of {its bias, its GEMM1 accumulator} lands last.
+    f32x16 accA, accB;
+    f32x4 bv[4];
+    u32x4 wf[KP1], w2f[2][NO], hf[2];
+    t4 rres[NO][4];
+    auto reads = [&](int g) {                              // operands of step g
+      read_b1(g, bv);
+      read_w1(g + 1 < NG ? g + 1 : g, wf);                 // (the last step's GEMM1 result is not used)
+      read_w2(g, w2f);
+    };
+    read_w1(0, wf);
+    mfma1(wf, accA);
+    reads(0);
+#pragma unroll 1
+    for (int g = 0; g < NG; g += 2) {
+      __builtin_amdgcn_sched_barrier(0);
+      gelu(accA, bv, hf);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma1(wf, accB);
+      mfma2(w2f, hf);
+      __builtin_amdgcn_sched_barrier(0);
+      reads(g + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      gelu(accB, bv, hf);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma1(wf, accA);
+      mfma2(w2f, hf);
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 2 < NG) {
+        reads(g + 2);
+      } else {                                             // residual rows: in flight under the last MFMAs
+#pragma unroll
+        for (int o = 0; o < NO; ++o)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) rres[o][q] = *(const t4*)(Rp + mld * C + 32 * o + 8 * q + 4 * lh);
+      }
+    }
+
+    // ---- epilogue: (acc2 + b2) * gamma + resid -> 16-bit, 8-byte pieces ----
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = 32 * o + 8 * q + 4 * lh;
+        const f32x4 bv = *(const f32x4*)(sB2 + n);
+        const f32x4 gv = *(const f32x4*)(sG + n);
+        t4 o4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = from_f<T>(fmaf(acc2[o][4 * q + e] + bv[e], gv[e], to_f(rres[o][q][e])));
+        if (m < a.M && (!(GCV_MLP_ABLATE & 8) || o4[0] == (T)12345.0f)) *(t4*)(Op + m * C + n) = o4;
+      }
+  }
+}
+
+template <typename T> int launch_fused_mlp_res(const MlpArgs& a, hipStream_t s);
+
+}  // namespace gcv

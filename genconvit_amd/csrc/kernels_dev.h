@@ -641,6 +641,10 @@ dwconv7_ln_v3_kernel(const T* __restrict__ x, const float* __restrict__ wdw, con
   }
 }
 
+// workgroup barrier for LDS traffic only.  __syncthreads() is fence + barrier: the fence waits for vmcnt(0), i.e. for
+// every global load and store the wave has in flight — exactly what a software-pipelined kernel must not do.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ------------------------------------------------------------------ K4 v4 (16-bit, C = 96): v3 + tile pipelining
 // One workgroup walks TPW consecutive 7x7 tiles (a tile row of the image).  The halo window of tile t+1 is fetched
 // into registers (4 x 16 B per thread) right after tile t's window has been handed to LDS, so the global / L2 latency
@@ -717,7 +721,7 @@ dwconv7_ln_v4_kernel(const T* __restrict__ x, const float* __restrict__ wdw, con
       const int idx = tid + i * NT;
       if (idx < NPIECE) *(u32x4*)(sIn + idx * 8) = v[i];
     }
-    __syncthreads();
+    lds_barrier();
     if (t + 1 < TPW && tile + 1 < ntiles) fetch(tile + 1);   // in flight until the next iteration's LDS write
 
     float acc[7];
@@ -744,10 +748,10 @@ dwconv7_ln_v4_kernel(const T* __restrict__ x, const float* __restrict__ wdw, con
           for (int j = 0; j < 4; ++j) acc[ox] = Dot2<T>::run(pp[ox + 2 * j], w2[j], acc[ox]);
       }
     }
-    __syncthreads();                                     // halo window is free: reuse it for LayerNorm
+    lds_barrier();                                     // halo window is free: reuse it for LayerNorm
 #pragma unroll
     for (int ox = 0; ox < 7; ++ox) sval[(rg * 7 + ox) * C + c] = acc[ox];
-    __syncthreads();
+    lds_barrier();
     {
       const int grp = tid >> 5, gl = tid & 31;
       for (int p = grp; p < 49; p += NT / 32) {
@@ -769,19 +773,19 @@ dwconv7_ln_v4_kernel(const T* __restrict__ x, const float* __restrict__ wdw, con
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int ox = 0; ox < 7; ++ox) {
       const int p = rg * 7 + ox;
       sOut[p * C + c] = (unsigned short)bits16<T>((acc[ox] - stats[2 * p]) * stats[2 * p + 1] * lw + lb);
     }
-    __syncthreads();
+    lds_barrier();
     for (int idx = tid; idx < 49 * CP; idx += NT) {
       const int p = idx / CP, pc = idx - p * CP;
       const int oy = y0 + p / 7, ox = x0 + p % 7;
       if (oy < H && ox < W) *(u32x4*)(y + ((img + (int64_t)oy * W + ox) * C + 8 * pc)) = *(const u32x4*)(sOut + p * C + 8 * pc);
     }
-    __syncthreads();                                     // staging is read out: the next halo may overwrite it
+    lds_barrier();                                     // staging is read out: the next halo may overwrite it
   }
 }
 

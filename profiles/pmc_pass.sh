@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: pmc_pass.sh <outdir> <microbench target> — three PMC passes (8 SQ counters each) over profiles/microbench.py
 # rocprofv3 --pmc runs are kept separate from kernel-trace runs (gpurun refuses mixing with sys/hip traces).
-out=$1; tgt=$2; R=${GRAFT_REPO_ROOT:-$PWD}
+out=$1; tgt=$2; R=${GRAFT_REPO_ROOT:-$PWD}; mkdir -p $R/$out
 cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
