@@ -18,7 +18,7 @@ def load(sub, name):
             d[k][0] += 1; d[k][1] += float(r["Counter_Value"])
     return d
 fe, wr = load("fetch", "FETCH_SIZE"), load("write", "WRITE_SIZE")
-fam = lambda k: "mfma_gemm" if ("gemm_glds_kernel" in k or "fused_mlp_kernel" in k or ("gemm_kernel" in k and "ELi0ELi0E" in k) or ("gemm_kernel" in k and "ELi0ELi1E" in k)) else ("dwconv7_ln" if "dwconv7_ln" in k else "other")
+fam = lambda k: "mfma_gemm" if ("gemm_glds_kernel" in k or "fused_mlp" in k or ("gemm_kernel" in k and "ELi0ELi0E" in k) or ("gemm_kernel" in k and "ELi0ELi1E" in k)) else ("dwconv7_ln" if "dwconv7_ln" in k else "other")
 res = {}
 for k in set(fe) | set(wr):
     f = res.setdefault(fam(k), {"dispatches": 0, "read_bytes": 0.0, "write_bytes": 0.0})
