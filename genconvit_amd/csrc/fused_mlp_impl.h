@@ -51,9 +51,10 @@ template <typename T> int launch_fused_mlp_res(const MlpArgs& a, hipStream_t s) 
     GCV_CHECK_HIP(hipFuncSetAttribute((const void*)fused_mlp_res_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_done = true;
   }
+  static const int nw = [] { const char* e = std::getenv("GCV_MLP_RES_WAVES"); return e ? std::atoi(e) : 8; }();
   const int wave_tiles = cdiv(a.M, 32);
-  const int nwg = cdiv(wave_tiles, 8) < 256 ? cdiv(wave_tiles, 8) : 256;    // one persistent workgroup per CU
-  hipLaunchKernelGGL((fused_mlp_res_kernel<T>), dim3(nwg), dim3(512), SMEM, s, a);
+  const int nwg = cdiv(wave_tiles, nw) < 256 ? cdiv(wave_tiles, nw) : 256;    // one persistent workgroup per CU
+  hipLaunchKernelGGL((fused_mlp_res_kernel<T>), dim3(nwg), dim3(64 * nw), SMEM, s, a);
   GCV_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -51,11 +51,17 @@ __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) 
   const int lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
 
+#if GCV_MLP_STAMPS
+#define RES_STAMP(slot) do { if (blockIdx.x < 64 && (threadIdx.x & 63) == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); if (threadIdx.x == 0) gcv_mlp_stamps[blockIdx.x * 16 + (slot)] = _t; if (threadIdx.x == 448) gcv_mlp_stamps[blockIdx.x * 16 + (slot) + 3] = _t; } } while (0)
+#else
+#define RES_STAMP(slot) do { } while (0)
+#endif
+  RES_STAMP(10);
   // ---- weights -> LDS, once ----
   {
     const unsigned char* g1 = (const unsigned char*)a.W1;
     const unsigned char* g2 = (const unsigned char*)a.W2c;
-    for (int idx = tid; idx < 2 * 384 * 12; idx += 512) {
+    for (int idx = tid; idx < 2 * 384 * 12; idx += (int)blockDim.x) {
       const int which = idx >= 384 * 12;
       const int k2 = which ? idx - 384 * 12 : idx;
       const int row = k2 / 12, k16 = k2 - row * 12;
@@ -63,10 +69,11 @@ __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) 
       *(u32x4*)(smem + (which ? MlpResSmem::kW2 : MlpResSmem::kW1) + row * ROW + mlp_res_swz(row, k16) * 16) = v;
     }
     float* sf = reinterpret_cast<float*>(smem + MlpResSmem::kB1);
-    for (int i = tid; i < 384 + 96 + 96; i += 512)
+    for (int i = tid; i < 384 + 96 + 96; i += (int)blockDim.x)
       sf[i] = i < 384 ? a.b1[i] : (i < 480 ? a.b2[i - 384] : a.gamma[i - 480]);
   }
   __syncthreads();
+  RES_STAMP(11);
 
   const T* __restrict__ Xp = (const T*)a.X;
   const T* Rp = (const T*)a.resid;
@@ -74,20 +81,33 @@ __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) 
   typedef T t4 __attribute__((ext_vector_type(4)));
 
   const int ntiles = (a.M + 31) / 32;
-  const int stride = (int)gridDim.x * 8;
+  const int nwaves = (int)blockDim.x >> 6;
+  const int stride = (int)gridDim.x * nwaves;
   // lane-constant parts of the fragment addresses: row r = 32*blk + lr has swizzle key (lr >> 2) & 3 (32*blk adds 0 mod 4
   // to r >> 2 ... only when blk*8 is a multiple of 4, which it is)
   const int key = (lr >> 2) & 3;
   const int rowoff = lr * ROW;
 
-  for (int tile = (int)blockIdx.x * 8 + wave; tile < ntiles; tile += stride) {
+  // x_ln fragments (k-step p, lane = token lr / k half lh).  The registers are dead once the last GEMM1 of a tile has
+  // issued, so the NEXT tile's rows are fetched there and land under this tile's tail and epilogue.
+  u32x4 xf[KP1];
+  auto load_x = [&](int tile) {
+    const int64_t mm = (int64_t)tile * 32 + lr;
+    const int64_t mmc = (GCV_MLP_ABLATE & 8) ? (int64_t)lr : (mm < a.M ? mm : (int64_t)a.M - 1);
+#pragma unroll
+    for (int p = 0; p < KP1; ++p) xf[p] = *(const u32x4*)(Xp + mmc * C + 16 * p + 8 * lh);
+  };
+  if ((int)blockIdx.x * nwaves + wave < ntiles) load_x((int)blockIdx.x * nwaves + wave);
+  int titer = 0;
+  for (int tile = (int)blockIdx.x * nwaves + wave; tile < ntiles; tile += stride, ++titer) {
+    if (titer == 2) GCV_STAMP(0);
+#if GCV_MLP_STAMPS
+    if (titer == 2 && blockIdx.x < 64 && threadIdx.x == 0) gcv_mlp_stamps[blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int64_t m = (int64_t)tile * 32 + lr;
     const int64_t mc = m < a.M ? m : (int64_t)a.M - 1;        // clamp: tail rows compute garbage, store nothing
     const int64_t mld = (GCV_MLP_ABLATE & 8) ? (int64_t)lr : mc;
 
-    u32x4 xf[KP1];                                             // x_ln fragments: k-step p, lane (token lr, half lh)
-#pragma unroll
-    for (int p = 0; p < KP1; ++p) xf[p] = *(const u32x4*)(Xp + mld * C + 16 * p + 8 * lh);
 
     f32x16 acc2[NO];
 #pragma unroll
@@ -95,11 +115,14 @@ __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[o][r] = 0.0f;
 
-    // One pipeline step per 32-wide hidden group g, written as three fenced phases so that LDS latency is paid once
-    // per group and not once per MFMA (left alone, hipcc emits ds_read -> s_waitcnt -> v_mfma chains):
-    //   reads : b1(g) (4), W1 fragments of group g+1 (6), W2 fragments of group g (6)      -> 16 ds_read_b128 in flight
-    //   VALU  : h(g) = GELU(acc1(g) + b1(g)) packed to two 16-byte B fragments               (fragments land meanwhile)
-    //   MFMA  : acc1(g+1) = W1[g+1] . x  (6),  acc2 += W2[:, g] . h(g)  (6)                 (runs under the other wave's GELU)
+    // Per-wave software pipeline over the 12 hidden groups of 32.  In steady state one step holds
+    //     12 MFMAs :  N += W1[g+1] . x   (N was pre-loaded with b1[g+1] straight from LDS, so the bias add is free)
+    //                 acc2 += W2[:, g-1] . h(g-1)
+    //     ~175 VALU:  h(g) = GELU(C)  packed to two 16-byte B fragments
+    // which are independent of each other, and sched_group_barrier interleaves them 1 MFMA : 15 VALU so the wave never
+    // sits out the 32 cycles an MFMA holds the matrix pipe (12 x 32 = 384 of ~1150 cycles per step when the MFMAs are
+    // issued back to back).  The LDS reads of the next step (b1 -> accumulator registers, W1 / W2 fragments) are
+    // issued at the end of a step, after the MFMAs that used the previous fragments.
     auto frag_off = [&](int k16) { return ((k16 & ~3) | ((k16 & 3) ^ key)) << 4; };
     auto read_w1 = [&](int g, u32x4 (&wf)[KP1]) {
       const unsigned char* base = sW1 + g * 32 * ROW + rowoff;
@@ -114,13 +137,15 @@ __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) 
 #pragma unroll
         for (int o = 0; o < NO; ++o) w2f[s][o] = *(const u32x4*)(base + 32 * o * ROW + frag_off(2 * (2 * j + s) + lh));
     };
-    auto read_b1 = [&](int g, f32x4 (&bv)[4]) {
+    auto read_b1 = [&](int g, f32x16& acc) {               // accumulator := bias of group g (token-on-lane layout)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bv[q] = *(const f32x4*)(sB1 + g * 32 + 8 * q + 4 * lh);
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *(const f32x4*)(sB1 + g * 32 + 8 * q + 4 * lh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * q + e] = bv[e];
+      }
     };
     auto mfma1 = [&](const u32x4 (&wf)[KP1], f32x16& acc1) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc1[r] = 0.0f;
 #pragma unroll
       for (int p = 0; p < KP1; ++p) Mfma<T>::run(wf[p], xf[p], acc1);
     };
@@ -130,14 +155,14 @@ __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) 
 #pragma unroll
         for (int o = 0; o < NO; ++o) Mfma<T>::run(w2f[s][o], hf[s], acc2[o]);
     };
-    auto gelu = [&](const f32x16& acc1, const f32x4 (&bv)[4], u32x4 (&hf)[2]) {
+    auto gelu = [&](const f32x16& acc1, u32x4 (&hf)[2]) {
 #pragma unroll
       for (int q0 = 0; q0 < 4; q0 += 2) {
         float hv[2][4];
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) hv[qq][e] = acc1[4 * (q0 + qq) + e] + bv[q0 + qq][e];
+          for (int e = 0; e < 4; ++e) hv[qq][e] = acc1[4 * (q0 + qq) + e];
         if (!(GCV_MLP_ABLATE & 1)) act4n<ACT_GELU, T, 2>(hv);
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
@@ -148,48 +173,64 @@ __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) 
         }
       }
     };
-
-    // Steady state of one step (group g; C / N are the ping-pong GEMM1 accumulators):
-    //     h = GELU(C + b1(g))  ->  N = W1[g+1] . x ,  acc2 += W2[:, g] . h  ->  issue the LDS reads of step g+1
-    // The reads are issued right after the MFMAs that consumed the previous fragments, so their latency runs under
-    // those MFMAs; the next GELU waits on whichever of {its bias, its GEMM1 accumulator} lands last.
-    f32x16 accA, accB;
-    f32x4 bv[4];
-    u32x4 wf[KP1], w2f[2][NO], hf[2];
-    t4 rres[NO][4];
-    auto reads = [&](int g) {                              // operands of step g
-      read_b1(g, bv);
-      read_w1(g + 1 < NG ? g + 1 : g, wf);                 // (the last step's GEMM1 result is not used)
+    // one steady-state step for group g: C holds GEMM1(g)+b1, N holds b1(g+1), hp = h(g-1), wf = W1(g+1), w2f = W2(g-1)
+    auto step = [&](int g, f32x16& Cacc, f32x16& Nacc, u32x4 (&hp)[2], u32x4 (&hc)[2], u32x4 (&wf)[KP1], u32x4 (&w2f)[2][NO]) {
+      __builtin_amdgcn_sched_barrier(0);
+      mfma1(wf, Nacc);
+      mfma2(w2f, hp);
+      gelu(Cacc, hc);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x002, 15, 0);   // 15 VALU
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      read_b1(g + 2 < NG ? g + 2 : NG - 1, Cacc);            // C's registers are free: they become the next N
+      read_w1(g + 2 < NG ? g + 2 : NG - 1, wf);
       read_w2(g, w2f);
+      __builtin_amdgcn_sched_barrier(0);
     };
+
+    f32x16 accA, accB;
+    u32x4 wf[KP1], w2f[2][NO], hfA[2], hfB[2];
+    read_b1(0, accA);
     read_w1(0, wf);
     mfma1(wf, accA);
-    reads(0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_b1(1, accB);
+    read_w1(1, wf);
+    mfma1(wf, accB);
+    __builtin_amdgcn_sched_barrier(0);
+    if (titer == 2) GCV_STAMP(1);
+    gelu(accA, hfA);                                        // h(0)
+    read_b1(2, accA);
+    read_w1(2, wf);
+    read_w2(0, w2f);
 #pragma unroll 1
-    for (int g = 0; g < NG; g += 2) {
-      __builtin_amdgcn_sched_barrier(0);
-      gelu(accA, bv, hf);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma1(wf, accB);
-      mfma2(w2f, hf);
-      __builtin_amdgcn_sched_barrier(0);
-      reads(g + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      gelu(accB, bv, hf);
-      __builtin_amdgcn_sched_barrier(0);
-      mfma1(wf, accA);
-      mfma2(w2f, hf);
-      __builtin_amdgcn_sched_barrier(0);
-      if (g + 2 < NG) {
-        reads(g + 2);
-      } else {                                             // residual rows: in flight under the last MFMAs
-#pragma unroll
-        for (int o = 0; o < NO; ++o)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) rres[o][q] = *(const t4*)(Rp + mld * C + 32 * o + 8 * q + 4 * lh);
-      }
+    for (int g = 1; g < NG - 1; g += 2) {
+      if (titer == 2 && g == 1) GCV_STAMP(2);
+      step(g, accB, accA, hfA, hfB, wf, w2f);               // odd g : C = B, N = A, h(g-1) in hfA -> h(g) in hfB
+      if (titer == 2 && g == 1) GCV_STAMP(3);
+      step(g + 1, accA, accB, hfB, hfA, wf, w2f);           // even g: C = A, N = B
+      if (titer == 2 && g == 1) GCV_STAMP(4);
     }
+    if (titer == 2) GCV_STAMP(5);
+    // tail: g = NG-1 sits in accB, h(NG-2) in hfA, w2f = W2(NG-2)
+    __builtin_amdgcn_sched_barrier(0);
+    if (tile + stride < ntiles) load_x(tile + stride);
+    t4 rres[NO][4];
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rres[o][q] = *(const t4*)(Rp + mld * C + 32 * o + 8 * q + 4 * lh);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma2(w2f, hfA);
+    gelu(accB, hfB);
+    __builtin_amdgcn_sched_barrier(0);
+    read_w2(NG - 1, w2f);
+    mfma2(w2f, hfB);
 
+    if (titer == 2) GCV_STAMP(7);
     // ---- epilogue: (acc2 + b2) * gamma + resid -> 16-bit, 8-byte pieces ----
 #pragma unroll
     for (int o = 0; o < NO; ++o)
@@ -203,7 +244,12 @@ __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) 
         for (int e = 0; e < 4; ++e) o4[e] = from_f<T>(fmaf(acc2[o][4 * q + e] + bv[e], gv[e], to_f(rres[o][q][e])));
         if (m < a.M && (!(GCV_MLP_ABLATE & 8) || o4[0] == (T)12345.0f)) *(t4*)(Op + m * C + n) = o4;
       }
+    if (titer == 2) GCV_STAMP(6);
+#if GCV_MLP_STAMPS
+    if (titer == 2 && blockIdx.x < 64 && threadIdx.x == 0) gcv_mlp_stamps[blockIdx.x * 16 + 9] = __builtin_amdgcn_s_memrealtime();
+#endif
   }
+  RES_STAMP(12);
 }
 
 template <typename T> int launch_fused_mlp_res(const MlpArgs& a, hipStream_t s);
