@@ -162,8 +162,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the HIP path")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # GCV_BENCH_FORCE_DIST=1 takes the RCCL path (init, gather, barrier, max-reduce) even with one rank: a way to
+    # rehearse the multi-GPU code on a one-GPU box
+    dist_on = world > 1 or os.environ.get("GCV_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if "RANK" not in os.environ:
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         torch.distributed.init_process_group("nccl", device_id=device)
     torch.set_grad_enabled(False)
     torch.set_num_threads(host_cores())
@@ -182,13 +188,13 @@ def main():
 
     def step():
         logits = model(x, eps=eps)
-        if world > 1:
+        if dist_on:
             logits = gdist.gather_logits(logits, n_global, nets)
         return _lib.vote(logits)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
@@ -201,7 +207,7 @@ def main():
         out = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -296,7 +302,7 @@ def main():
         if swin is not None:
             line["swin_embedder"] = swin
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
