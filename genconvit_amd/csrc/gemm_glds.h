@@ -42,27 +42,34 @@ __device__ unsigned long long gcv_glds_stamps[4096 * 8];
 #else
 #define GLDS_STAMP(i) do { } while (0)
 #endif
-constexpr int kGldsBM = 128, kGldsBN = 192, kGldsBKB = 64, kGldsStages = GCV_GLDS_STAGES;
+constexpr int kGldsBM = 128, kGldsBN = 192;
+// ring geometry by bytes per LDS row: 64 B (32 k) x 4 stages, or 128 B (64 k, a whole 128-byte line per row) x 2 stages —
+// both 80 KB; whole-line fetches fill LDS 1.3-1.4x faster (profiles/micro/lds_dma_rate.hip), so 128 is used when K % 64 == 0
+template <int BKB> struct GldsRing { static constexpr int stages = BKB == 64 ? GCV_GLDS_STAGES : 2; };
 
-template <typename T> struct GldsSmem {
-  static constexpr int kStage = (kGldsBM + kGldsBN) * kGldsBKB;            // 20480
-  static constexpr int kMain = kGldsStages * kStage;                       // 81920
+template <typename T, int BKB = 64> struct GldsSmem {
+  static constexpr int kStage = (kGldsBM + kGldsBN) * BKB;                 // 20480 / 40960
+  static constexpr int kMain = GldsRing<BKB>::stages * kStage;             // 81920
   static constexpr int kEpiRow = kGldsBN / 2 + 4;                          // dwords per staged row: 16-B aligned rows
   static constexpr int kEpiBG = kGldsBM * kEpiRow * 4;                      // byte offset of the bias|gamma broadcast rows
   static constexpr int kEpi = kEpiBG + 2 * kGldsBN * 4;
   static constexpr int bytes = kMain > kEpi ? kMain : kEpi;
 };
 
-template <typename T, int EPI, int ACT>
+template <typename T, int EPI, int ACT, int BKB = 64>
 __global__ void __launch_bounds__(256, 2) gemm_glds_kernel(const GemmArgs g) {
   static_assert(sizeof(T) == 2, "LDS-DMA GEMM is built for 16-bit storage");
   static_assert(EPI == EPI_BIAS_ACT || EPI == EPI_RESID, "epilogues: bias+act, layer-scale residual");
-  constexpr int BM = kGldsBM, BN = kGldsBN, BKB = kGldsBKB, S = kGldsStages;
-  constexpr int EPC = 8, CPR = BKB / 16, BK = CPR * EPC;          // 4 chunks, 32 k per tile
-  constexpr int STAGE = GldsSmem<T>::kStage;
+  static_assert(BKB == 64 || BKB == 128, "LDS rows are 64 or 128 bytes");
+  constexpr int BM = kGldsBM, BN = kGldsBN, S = GldsRing<BKB>::stages;
+  constexpr int EPC = 8, CPR = BKB / 16, BK = CPR * EPC;          // 4 (8) chunks, 32 (64) k per tile
+  constexpr int RPI = 64 / CPR;                                   // rows per DMA wave-instruction: 16 (8)
+  constexpr int STAGE = GldsSmem<T, BKB>::kStage;
+  // bank swizzle key of a row: the 16 lanes of a ds_read_b128 group must land on 16 distinct 16-byte units mod 16
+  auto swz = [](int row) { return CPR == 4 ? ((row >> 2) & 3) : ((row >> 1) & 7); };
   constexpr int A_BYTES = BM * BKB;
-  constexpr int NQ = STAGE / 1024;                                // DMA wave-instructions per stage (20)
-  constexpr int QPW = NQ / 4;                                     // per wave (5)
+  constexpr int NQ = STAGE / 1024;                                // DMA wave-instructions per stage (20 / 40)
+  constexpr int QPW = NQ / 4;                                     // per wave (5 / 10)
   constexpr int MI = 2, NI = 3;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -90,15 +97,15 @@ __global__ void __launch_bounds__(256, 2) gemm_glds_kernel(const GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < QPW; ++i) {
     const int q = wave + 4 * i;
-    const int rl = q * 16 + (lane >> 2);                 // row inside the stage image
-    const int phys = lane & 3;
+    const int rl = q * RPI + lane / CPR;                 // row inside the stage image
+    const int phys = lane % CPR;
     if (rl < BM) {
-      const int c = phys ^ ((rl >> 2) & 3);
+      const int c = phys ^ swz(rl);
       const int m = min(m0 + rl, g.M - 1);
       src[i] = (const T*)g.A + (int64_t)m * g.lda + c * EPC;
     } else {
       const int rb = rl - BM;
-      const int c = phys ^ ((rb >> 2) & 3);
+      const int c = phys ^ swz(rb);
       const int n = min(n0 + rb, g.N - 1);
       src[i] = (const T*)g.Wt + (int64_t)n * g.K + c * EPC;
     }
@@ -131,12 +138,12 @@ __global__ void __launch_bounds__(256, 2) gemm_glds_kernel(const GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const int row = wm0 + i * 32 + lr;
-        af[i] = *(const u32x4*)(sA + row * BKB + ((c ^ ((row >> 2) & 3)) << 4));
+        af[i] = *(const u32x4*)(sA + row * BKB + ((c ^ swz(row)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const int row = wn0 + j * 32 + lr;
-        bf[j] = *(const u32x4*)(sB + row * BKB + ((c ^ ((row >> 2) & 3)) << 4));
+        bf[j] = *(const u32x4*)(sB + row * BKB + ((c ^ swz(row)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -179,10 +186,10 @@ __global__ void __launch_bounds__(256, 2) gemm_glds_kernel(const GemmArgs g) {
   // Every global read the epilogue needs is in flight at once (the residual: 24 independent 8-byte loads per lane,
   // issued before the barrier) or already in registers (bias / gamma), so it pays ONE memory latency, not one
   // per 4-channel group.
-  constexpr int SROW = GldsSmem<T>::kEpiRow;
+  constexpr int SROW = GldsSmem<T, BKB>::kEpiRow;
   typedef T t4 __attribute__((ext_vector_type(4)));
   uint32_t* sC = reinterpret_cast<uint32_t*>(smem);
-  float* sBG = reinterpret_cast<float*>(smem + GldsSmem<T>::kEpiBG);
+  float* sBG = reinterpret_cast<float*>(smem + GldsSmem<T, BKB>::kEpiBG);
   T* Cp = (T*)g.C;
   t4 rres[EPI == EPI_RESID ? MI : 1][EPI == EPI_RESID ? NI : 1][4];
   if (EPI == EPI_RESID && !(GCV_GLDS_ABLATE & 4)) {

@@ -6,18 +6,24 @@
 
 namespace gcv {
 
-template <typename T, int EPI, int ACT> static int launch_glds_cfg(const GemmArgs& g, hipStream_t s) {
-  constexpr int SMEM = GldsSmem<T>::bytes;
+template <typename T, int EPI, int ACT, int BKB> static int launch_glds_bkb(const GemmArgs& g, hipStream_t s) {
+  constexpr int SMEM = GldsSmem<T, BKB>::bytes;
   static bool attr_done = false;
   if (!attr_done) {
-    GCV_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, ACT>,
+    GCV_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, ACT, BKB>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_done = true;
   }
   const int ntm = cdiv(g.M, kGldsBM), ntn = g.N / kGldsBN;
-  hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, ACT>), dim3(ntm * ntn), dim3(256), SMEM, s, g);
+  hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, ACT, BKB>), dim3(ntm * ntn), dim3(256), SMEM, s, g);
   GCV_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+template <typename T, int EPI, int ACT> static int launch_glds_cfg(const GemmArgs& g, hipStream_t s) {
+  static const bool line64 = std::getenv("GCV_GLDS_ROW64") != nullptr;    // A/B switch: force the 64-byte-row ring
+  if (g.K % 64 == 0 && g.K >= 512 && !line64) return launch_glds_bkb<T, EPI, ACT, 128>(g, s);   // (K = 384: 6 stages, the 4-deep ring wins)
+  return launch_glds_bkb<T, EPI, ACT, 64>(g, s);
 }
 
 template <typename T> bool gemm_glds_applicable(const GemmArgs& g, int a_mode, int epi) {
