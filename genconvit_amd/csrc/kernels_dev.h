@@ -444,6 +444,22 @@ __global__ void __launch_bounds__(192) dwconv7_ln_v2_kernel(const T* __restrict_
   }
 }
 
+// taps (49, C) fp32 -> [28][C] dwords of packed 16-bit pairs (tap(ky,2j), tap(ky,2j+1)), tap(ky,7) = 0: the LDS image
+// the v3 kernel works from.  Built once when the weights are loaded (per tile it cost 11 % of the C=96 kernel).
+template <typename T>
+__global__ void __launch_bounds__(256) pack_dw_taps_kernel(const float* __restrict__ wdw, uint32_t* __restrict__ out, int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 28 * C) return;
+  const int c = i % C, kj = i / C;
+  const int ky = kj >> 2, j = kj & 3;
+  const uint32_t lo = bits16<T>(wdw[(ky * 7 + 2 * j) * C + c]);
+  const uint32_t hi = (j < 3) ? bits16<T>(wdw[(ky * 7 + 2 * j + 1) * C + c]) : 0u;
+  out[i] = lo | (hi << 16);
+}
+
+#ifndef GCV_DW_ABLATE
+#define GCV_DW_ABLATE 0     // diagnostics: 1 one tap row, 2 no LN stats, 4 no tap packing, 8 no halo loads, 16 no stores
+#endif
 // ------------------------------------------------------------------ K4 v3 (16-bit, C = 96 / 192)
 // Occupancy-first decomposition of the same op: one workgroup = one 7x7 tile, one THREAD = one channel
 // of RPT output rows (7 x RPT accumulators), i.e. 672 (C=96) / 768 (C=192) threads per tile instead of
@@ -455,7 +471,7 @@ template <typename T, int C, int RPT, bool DOT2>
 __global__ void __launch_bounds__(((7 + RPT - 1) / RPT) * C)
 dwconv7_ln_v3_kernel(const T* __restrict__ x, const float* __restrict__ wdw, const float* __restrict__ bdw,
                      const float* __restrict__ lnw, const float* __restrict__ lnb, T* __restrict__ y, int nimg, int H,
-                     int W, float eps) {
+                     int W, float eps, const uint32_t* __restrict__ wpk) {
   static_assert(sizeof(T) == 2 && (C == 96 || C == 192), "v3 covers 16-bit storage, C = 96 / 192");
   constexpr int NRG = (7 + RPT - 1) / RPT;            // row groups (threads per channel)
   constexpr int NT = NRG * C;
@@ -484,7 +500,10 @@ dwconv7_ln_v3_kernel(const T* __restrict__ x, const float* __restrict__ wdw, con
   const int64_t img = (int64_t)b * H * W;
 
   // ---- taps -> LDS as (tap(ky,2j), tap(ky,2j+1)) pairs, tap(ky,7) = 0 ----
-  for (int i = tid; W_IN_LDS && i < 28 * C; i += NT) {
+  if (W_IN_LDS && wpk) {                               // pre-packed taps: 28*C dwords = one 16-byte piece per thread
+    if (tid < 28 * C / 4) *(u32x4*)(sW2 + 4 * tid) = *(const u32x4*)(wpk + 4 * tid);
+  }
+  for (int i = tid; W_IN_LDS && !wpk && !(GCV_DW_ABLATE & 4) && i < 28 * C; i += NT) {
     const int c = i % C, kj = i / C;
     const int ky = kj >> 2, j = kj & 3;
     const uint32_t lo = bits16<T>(wdw[(ky * 7 + 2 * j) * C + c]);
@@ -504,7 +523,7 @@ dwconv7_ln_v3_kernel(const T* __restrict__ x, const float* __restrict__ wdw, con
       const int iy = y0 + r - 3, ix = x0 + sx - 3;
       const bool ok = idx < NPIECE && iy >= 0 && iy < H && ix >= 0 && ix < W;
       const int64_t off = ok ? ((img + (int64_t)iy * W + ix) * C + 8 * pc) : 0;
-      const u32x4 t = *(const u32x4*)(x + off);
+      const u32x4 t = (GCV_DW_ABLATE & 8) ? u32x4{(uint32_t)idx, 1u, 2u, 3u} : *(const u32x4*)(x + off);
       const uint32_t m = ok ? 0xffffffffu : 0u;
       v[i] = u32x4{t[0] & m, t[1] & m, t[2] & m, t[3] & m};
     }
@@ -534,6 +553,8 @@ dwconv7_ln_v3_kernel(const T* __restrict__ x, const float* __restrict__ wdw, con
     for (int k = 0; k < 28; ++k) {
       if (W_IN_LDS) {
         w2[k] = sW2[k * C + c];
+      } else if (wpk) {
+        w2[k] = wpk[k * C + c];
       } else {
         const int ky = k >> 2, j = k & 3;
         const uint32_t lo = bits16<T>(wdw[(ky * 7 + 2 * j) * C + c]);
@@ -631,6 +652,147 @@ dwconv7_ln_v3_kernel(const T* __restrict__ x, const float* __restrict__ wdw, con
           sOut[p * C + c] = (unsigned short)bits16<T>((acc[rr][ox] - stats[2 * p]) * stats[2 * p + 1] * lw + lb);
         }
       }
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 49 * CP; idx += NT) {
+    const int p = idx / CP, pc = idx - p * CP;
+    const int oy = y0 + p / 7, ox = x0 + p % 7;
+    if (oy < H && ox < W && (!(GCV_DW_ABLATE & 16) || sOut[p * C + 8 * pc] == 0x1234)) *(u32x4*)(y + ((img + (int64_t)oy * W + ox) * C + 8 * pc)) = *(const u32x4*)(sOut + p * C + 8 * pc);
+  }
+}
+
+// ------------------------------------------------------------------ K4 v5 (16-bit, C = 96): two channels per thread
+// Same tile decomposition as v3 (one workgroup = one 7x7 tile, LDS halo [13x13][C], taps as packed pairs), but a
+// thread owns a channel PAIR of one output row: every LDS access moves 4 or 8 bytes instead of 2 or 4 (half the LDS
+// instructions per output), the workgroup is 336 threads = 6 waves instead of 11, and three workgroups share a CU
+// (18 waves, 130 KB LDS) instead of two — the five barriers of a tile then have two other tiles to hide behind.
+template <typename T, int C>
+__global__ void __launch_bounds__(7 * C / 2, 5)
+dwconv7_ln_v5_kernel(const T* __restrict__ x, const float* __restrict__ wdw, const float* __restrict__ bdw,
+                     const float* __restrict__ lnw, const float* __restrict__ lnb, T* __restrict__ y, int nimg, int H,
+                     int W, float eps) {
+  static_assert(sizeof(T) == 2 && C == 96, "v5 covers 16-bit storage, C = 96");
+  constexpr int HP = C / 2;                           // channel pairs
+  constexpr int NT = 7 * HP;                          // 336 threads
+  constexpr int CP = C / 8;                           // 16-byte pieces per pixel
+  constexpr int IN_BYTES = 169 * C * 2;
+  constexpr int STAT_OFF = 49 * C * 4;
+  constexpr int OUT_OFF = (STAT_OFF + 49 * 8 + 255) & ~255;
+  static_assert(OUT_OFF + 49 * C * 2 <= IN_BYTES, "LN / output staging must fit in the halo window");
+  extern __shared__ __attribute__((aligned(16))) unsigned char dw5_lds[];
+  unsigned short* sIn = reinterpret_cast<unsigned short*>(dw5_lds);
+  float* sval = reinterpret_cast<float*>(dw5_lds);
+  float* stats = reinterpret_cast<float*>(dw5_lds + STAT_OFF);
+  unsigned short* sOut = reinterpret_cast<unsigned short*>(dw5_lds + OUT_OFF);
+  uint32_t* sW2 = reinterpret_cast<uint32_t*>(dw5_lds + IN_BYTES);     // [28][C] packed tap pairs
+
+  const int tid = threadIdx.x;
+  const int tiles_x = (W + 6) / 7, tiles_y = (H + 6) / 7;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = tile % tiles_x, t2 = tile / tiles_x;
+  const int ty = t2 % tiles_y, b = t2 / tiles_y;
+  const int x0 = tx * 7, y0 = ty * 7;
+  const int64_t img = (int64_t)b * H * W;
+
+  for (int i = tid; i < 28 * C; i += NT) {
+    const int c = i % C, kj = i / C;
+    const int ky = kj >> 2, j = kj & 3;
+    const uint32_t lo = bits16<T>(wdw[(ky * 7 + 2 * j) * C + c]);
+    const uint32_t hi = (j < 3) ? bits16<T>(wdw[(ky * 7 + 2 * j + 1) * C + c]) : 0u;
+    sW2[i] = lo | (hi << 16);
+  }
+  constexpr int NPIECE = 169 * CP;
+  constexpr int NIT = (NPIECE + NT - 1) / NT;
+  {
+    u32x4 v[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int idx = tid + i * NT;
+      const int pix = idx / CP, pc = idx - pix * CP;
+      const int r = pix / 13, sx = pix - r * 13;
+      const int iy = y0 + r - 3, ix = x0 + sx - 3;
+      const bool ok = idx < NPIECE && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const int64_t off = ok ? ((img + (int64_t)iy * W + ix) * C + 8 * pc) : 0;
+      const u32x4 t = *(const u32x4*)(x + off);
+      const uint32_t m = ok ? 0xffffffffu : 0u;
+      v[i] = u32x4{t[0] & m, t[1] & m, t[2] & m, t[3] & m};
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int idx = tid + i * NT;
+      if (idx < NPIECE) *(u32x4*)(sIn + idx * 8) = v[i];
+    }
+  }
+  __syncthreads();
+
+  const int rg = tid / HP, cp = tid - rg * HP;          // output row, channel pair
+  const int c0 = 2 * cp;
+  float acc[2][7];
+  {
+    const float2 bv = *(const float2*)(bdw + c0);
+#pragma unroll
+    for (int ox = 0; ox < 7; ++ox) { acc[0][ox] = bv.x; acc[1][ox] = bv.y; }
+  }
+  const uint32_t* sIn32 = reinterpret_cast<const uint32_t*>(sIn);
+#pragma unroll
+  for (int ky = 0; ky < 7; ++ky) {
+    const int r = rg + ky;
+    uint2 w2[4];                                        // taps (ky, 2j..2j+1) of both channels
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w2[j] = *(const uint2*)(sW2 + (ky * 4 + j) * C + c0);
+    uint32_t raw[14];                                   // (x[c0], x[c1]) at window column s
+#pragma unroll
+    for (int s = 0; s < 13; ++s) raw[s] = sIn32[((r * 13 + s) * C + c0) >> 1];
+    raw[13] = 0u;
+#pragma unroll
+    for (int ox = 0; ox < 7; ++ox) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int s = ox + 2 * j;
+        const uint32_t p0 = __builtin_amdgcn_perm(raw[s + 1], raw[s], 0x05040100u);   // (x_c0[s], x_c0[s+1])
+        const uint32_t p1 = __builtin_amdgcn_perm(raw[s + 1], raw[s], 0x07060302u);   // (x_c1[s], x_c1[s+1])
+        acc[0][ox] = Dot2<T>::run(p0, w2[j].x, acc[0][ox]);
+        acc[1][ox] = Dot2<T>::run(p1, w2[j].y, acc[1][ox]);
+      }
+    }
+  }
+  __syncthreads();                                     // halo window is free: reuse it for LayerNorm
+#pragma unroll
+  for (int ox = 0; ox < 7; ++ox) *(float2*)(sval + (rg * 7 + ox) * C + c0) = make_float2(acc[0][ox], acc[1][ox]);
+  __syncthreads();
+  {
+    const int grp = tid >> 5, gl = tid & 31;
+    for (int p = grp; p < 49 && grp < NT / 32; p += NT / 32) {
+      const float* row = sval + p * C;
+      float s = 0.0f;
+#pragma unroll
+      for (int k = 0; k < C / 32; ++k) s += row[gl + 32 * k];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      const float mean = s * (1.0f / C);
+      float q = 0.0f;
+#pragma unroll
+      for (int k = 0; k < C / 32; ++k) { const float d = row[gl + 32 * k] - mean; q = fmaf(d, d, q); }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+      if (gl == 0) {
+        stats[2 * p] = mean;
+        stats[2 * p + 1] = 1.0f / sqrtf(q * (1.0f / C) + eps);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const float2 lw = *(const float2*)(lnw + c0), lb = *(const float2*)(lnb + c0);
+    uint32_t* sOut32 = reinterpret_cast<uint32_t*>(sOut);
+#pragma unroll
+    for (int ox = 0; ox < 7; ++ox) {
+      const int p = rg * 7 + ox;
+      const float2 st = *(const float2*)(stats + 2 * p);
+      const uint32_t lo = bits16<T>((acc[0][ox] - st.x) * st.y * lw.x + lb.x);
+      const uint32_t hi = bits16<T>((acc[1][ox] - st.x) * st.y * lw.y + lb.y);
+      sOut32[(p * C + c0) >> 1] = lo | (hi << 16);
     }
   }
   __syncthreads();

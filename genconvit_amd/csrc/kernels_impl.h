@@ -58,7 +58,7 @@ static int launch_dw_v2(const T* x, const float* wdw, const float* bdw, const fl
 
 template <typename T, int C, int RPT, bool DOT2>
 static int launch_dw_v3(const T* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb, T* y,
-                        int nimg, int H, int W, float eps, hipStream_t s) {
+                        int nimg, int H, int W, float eps, hipStream_t s, const uint32_t* wpk) {
   constexpr int NT = ((7 + RPT - 1) / RPT) * C;
   constexpr int LDS = 169 * C * 2 + (C == 96 ? 28 * C * 4 : 0);
   static bool attr_set = false;
@@ -70,7 +70,7 @@ static int launch_dw_v3(const T* x, const float* wdw, const float* bdw, const fl
   }
   const int tiles = nimg * cdiv(H, 7) * cdiv(W, 7);
   hipLaunchKernelGGL((dwconv7_ln_v3_kernel<T, C, RPT, DOT2>), dim3(tiles), dim3(NT), LDS, s, x, wdw, bdw, lnw, lnb, y, nimg, H,
-                     W, eps);
+                     W, eps, DOT2 ? wpk : nullptr);
   GCV_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -86,31 +86,53 @@ static int launch_dw_v4(const T* x, const float* wdw, const float* bdw, const fl
   return 0;
 }
 
-// 5: v4 (tile-pipelined v3, C = 96), 0: v3 + dot2 (default for 16-bit C<=192), 4: v3 with fp32 FMA taps, 1: v2 + dot2, 2: v1 everywhere,
+template <typename T, int C>
+static int launch_dw_v5(const T* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb, T* y,
+                        int nimg, int H, int W, float eps, hipStream_t s) {
+  constexpr int LDS = 169 * C * 2 + 28 * C * 4;
+  const int tiles = nimg * cdiv(H, 7) * cdiv(W, 7);
+  hipLaunchKernelGGL((dwconv7_ln_v5_kernel<T, C>), dim3(tiles), dim3(7 * C / 2), LDS, s, x, wdw, bdw, lnw, lnb, y, nimg, H, W,
+                     eps);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// 7: v5 (two channels per thread, C = 96), 5: v4 (tile-pipelined v3, C = 96), 0: v3 + dot2 (default for 16-bit C<=192), 4: v3 with fp32 FMA taps, 1: v2 + dot2, 2: v1 everywhere,
 // 3: v2 with fp32 FMA taps (env GCV_DWCONV_MODE, A/B switch for profiling)
 static inline int dwconv_mode() {
   static const int mode = [] { const char* e = std::getenv("GCV_DWCONV_MODE"); return e ? std::atoi(e) : 0; }();
   return mode;
 }
 
+template <typename T> int launch_pack_dw_taps(const float* wdw, uint32_t* out, int C, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    hipLaunchKernelGGL((pack_dw_taps_kernel<T>), dim3(cdiv(28 * C, 256)), dim3(256), 0, s, wdw, out, C);
+    GCV_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
+  set_error("packed dw taps exist for 16-bit storage only");
+  return -3;
+}
+
 template <typename T>
 int launch_dwconv7_ln(const T* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb, T* y,
-                      int nimg, int H, int W, int C, float eps, hipStream_t s) {
+                      int nimg, int H, int W, int C, float eps, hipStream_t s, const uint32_t* wpk) {
   GCV_REQUIRE(nimg > 0 && H > 0 && W > 0, "dwconv: empty");
   if constexpr (sizeof(T) == 2) {
     const int mode = dwconv_mode();
     if (mode != 2 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0) {
       if (C == 96) {
+        if (mode == 7) return launch_dw_v5<T, 96>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
         if (mode == 5) return launch_dw_v4<T, 96, 8>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
         if (mode == 6) return launch_dw_v4<T, 96, 4>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
-        if (mode == 0) return launch_dw_v3<T, 96, 1, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
-        if (mode == 4) return launch_dw_v3<T, 96, 1, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
+        if (mode == 0) return launch_dw_v3<T, 96, 1, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
+        if (mode == 4) return launch_dw_v3<T, 96, 1, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
         return mode == 1 ? launch_dw_v2<T, 96, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s)
                          : launch_dw_v2<T, 96, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
       }
       if (C == 192) {
-        if (mode == 0) return launch_dw_v3<T, 192, 2, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
-        if (mode == 4) return launch_dw_v3<T, 192, 2, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
+        if (mode == 0) return launch_dw_v3<T, 192, 2, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
+        if (mode == 4) return launch_dw_v3<T, 192, 2, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
         return mode == 1 ? launch_dw_v2<T, 192, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s)
                          : launch_dw_v2<T, 192, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
       }
@@ -278,8 +300,9 @@ template <typename T> int launch_preprocess(const unsigned char* u8, T* out, int
 #define GCV_INSTANTIATE_KERNELS(T)                                                                                    \
   template int launch_stem_ln<T>(const T*, int64_t, int64_t, int64_t, int64_t, const float*, const float*,            \
                                  const float*, const float*, T*, int, int, int, float, hipStream_t);                  \
+  template int launch_pack_dw_taps<T>(const float*, uint32_t*, int, hipStream_t);                                    \
   template int launch_dwconv7_ln<T>(const T*, const float*, const float*, const float*, const float*, T*, int, int,   \
-                                    int, int, float, hipStream_t);                                                    \
+                                    int, int, float, hipStream_t, const uint32_t*);                                   \
   template int launch_ln_patchify<T>(const T*, const float*, const float*, T*, int, int, int, int, float, hipStream_t); \
   template int launch_layernorm_rows<T>(const T*, const float*, const float*, T*, int64_t, int, float, hipStream_t);  \
   template int launch_pool_ln<T>(const T*, const float*, const float*, T*, int, int, int, float, hipStream_t);        \

@@ -94,6 +94,7 @@ template <typename T> struct CnxBlockW {
   float *dw_w, *dw_b, *ln_w, *ln_b, *fc1_b, *fc2_b, *gamma;
   T *fc1_w, *fc2_w;
   T* fc2_wc;       // 16-bit, C <= 192: W2 packed for the fused MLP kernel (else null)
+  uint32_t* dw_wpk; // 16-bit, C <= 192: dw taps as packed pairs [28][C] for dwconv7_ln_v3_kernel (else null)
 };
 template <typename T> struct CnxW {
   float *stem_w, *stem_b, *stem_lnw, *stem_lnb;
@@ -308,6 +309,15 @@ template <typename T> struct NetImpl : NetBase {
           for (int c = 0; c < C; ++c)
             for (int q = 0; q < 49; ++q) t[(size_t)q * C + c] = v[(size_t)c * 49 + q];
           GCV_UP(k.dw_w, st, t);
+          k.dw_wpk = nullptr;
+          if constexpr (sizeof(T) == 2) {
+            if (C <= 192) {
+              k.dw_wpk = (uint32_t*)st.raw((size_t)28 * C * 4);
+              if (!k.dw_wpk) { set_error("hipMalloc failed for packed dw taps"); return -5; }
+              GCV_TRY(launch_pack_dw_taps<T>(k.dw_w, k.dw_wpk, C, nullptr));
+              GCV_CHECK_HIP(hipDeviceSynchronize());
+            }
+          }
         }
         GCV_TRY(up_f32(w, b + "conv_dw.bias", C, st, k.dw_b));
         GCV_TRY(up_f32(w, b + "norm.weight", C, st, k.ln_w));
@@ -522,7 +532,7 @@ template <typename T> struct NetImpl : NetBase {
         for (int s = 0; s < nseg; ++s) {
           GCV_TRY(run("cnx.dwconv7_ln", 2.0 * 49 * m[s] * C, 2.0 * sizeof(T) * (double)m[s] * C + 49.0 * C * 4, [&] {
             return launch_dwconv7_ln<T>(X + moff[s] * C, k.dw_w, k.dw_b, k.ln_w, k.ln_b, Y + moff[s] * C, segs[s].n,
-                                        h[s], wd[s], C, 1e-6f, cur);
+                                        h[s], wd[s], C, 1e-6f, cur, k.dw_wpk);
           }));
         }
         if constexpr (sizeof(T) == 2) {
