@@ -501,7 +501,7 @@ dwconv7_ln_v3_kernel(const T* __restrict__ x, const float* __restrict__ wdw, con
 
   // ---- taps -> LDS as (tap(ky,2j), tap(ky,2j+1)) pairs, tap(ky,7) = 0 ----
   if (W_IN_LDS && wpk) {                               // pre-packed taps: 28*C dwords = one 16-byte piece per thread
-    if (tid < 28 * C / 4) *(u32x4*)(sW2 + 4 * tid) = *(const u32x4*)(wpk + 4 * tid);
+    for (int i = tid; i < 28 * C / 4; i += NT) *(u32x4*)(sW2 + 4 * i) = *(const u32x4*)(wpk + 4 * i);
   }
   for (int i = tid; W_IN_LDS && !wpk && !(GCV_DW_ABLATE & 4) && i < 28 * C; i += NT) {
     const int c = i % C, kj = i / C;

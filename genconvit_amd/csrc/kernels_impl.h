@@ -122,10 +122,11 @@ int launch_dwconv7_ln(const T* x, const float* wdw, const float* bdw, const floa
     const int mode = dwconv_mode();
     if (mode != 2 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0) {
       if (C == 96) {
+        if (mode == 8) return launch_dw_v3<T, 96, 1, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
         if (mode == 7) return launch_dw_v5<T, 96>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
         if (mode == 5) return launch_dw_v4<T, 96, 8>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
         if (mode == 6) return launch_dw_v4<T, 96, 4>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
-        if (mode == 0) return launch_dw_v3<T, 96, 1, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
+        if (mode == 0) return launch_dw_v3<T, 96, 2, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);   // two rows per thread: 384 threads, 3 workgroups per CU
         if (mode == 4) return launch_dw_v3<T, 96, 1, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
         return mode == 1 ? launch_dw_v2<T, 96, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s)
                          : launch_dw_v2<T, 96, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
