@@ -201,6 +201,32 @@ def test_vae_16bit_delta_vs_fp32_oracle(dtype, bound, golden):
 
 
 # ----------------------------------------------------------------------------- Swin-T embedder (row A6)
+def test_full_size_config4_genconvit_batch128_fp16(golden):
+    """BASELINE.json configs[3]: genconvit, batch 128, fp16 — the batch size at which the large-M kernels run
+    (LDS-resident fused MLP, 128-byte-row LDS-DMA GEMM).  Frames are independent, so rows of the B=128 result must
+    agree with the same frames pushed through as a batch of 4 (other kernels, other tile shapes), and the first four
+    frames with the reference's fp32 golden within the fp16 bound."""
+    x = synth.make_frames(128, name="frames")
+    x4 = synth.make_frames(4)
+    eps = torch.cat([torch.from_numpy(golden["vae_eps"]), synth.make_eps(124, name="cfg4")]).cuda()
+    assert torch.equal(x[:4], x4), "synthetic frames are index-addressed"
+    g = GenConViT.from_modules(ed_model(torch.float16), vae_model(torch.float16), net="genconvit")
+    big = g(x.cuda(), eps=eps).float().cpu()
+    assert big.shape == (256, 2) and torch.isfinite(big).all()
+    small = g(x4.cuda(), eps=eps[:4]).float().cpu()
+    d_ed = (big[0:4] - small[0:4]).abs().max().item()
+    d_vae = (big[128:132] - small[4:8]).abs().max().item()
+    e_ed = np.abs(big[0:4].numpy() - golden["ed_logits"]).max()
+    e_vae = np.abs(big[128:132].numpy() - golden["vae_logits"]).max()
+    print(f"\ngenconvit fp16 B=128: rows vs B=4 run: ed {d_ed:.2e} vae {d_vae:.2e}; vs fp32 golden: ed {e_ed:.2e} vae {e_vae:.2e}")
+    assert d_ed <= 1e-2 and d_vae <= 1.5e-2
+    assert e_ed <= 2e-2 and e_vae <= 3e-2
+    # shards of 32 reassemble to the same rows (the multi-GPU partition, run back to back on one GPU)
+    parts = [g(x[i:i + 32].cuda(), eps=eps[i:i + 32]).float().cpu() for i in range(0, 128, 32)]
+    re = torch.cat([torch.cat([p[:32] for p in parts]), torch.cat([p[32:] for p in parts])])
+    assert (re - big).abs().max().item() <= 1.5e-2
+
+
 def swin_model(dtype=torch.float32):
     key = ("swin", dtype)
     if key not in _CACHE:
