@@ -32,6 +32,8 @@ class GenConViTED(HipModule):
     @torch.no_grad()
     def forward(self, images):
         images = self._prep_input(images)
+        if images.shape[0] == 0:                      # an empty batch is an empty result, as with the reference's nn.Modules
+            return torch.empty((0, 2), dtype=torch.float32, device=images.device)
         return self._get_handle(images.shape[0]).ed_forward(images)
 
     def backbone_forward(self, images):

@@ -39,6 +39,10 @@ class GenConViTVAE(HipModule):
     def forward(self, x, eps=None, want_recon=True, want_mse=False, want_kl=False):
         x = self._prep_input(x)
         B = x.shape[0]
+        if B == 0:                                    # empty batch -> empty outputs (no RNG draw, no launch)
+            self.kl, self.mse = None, None
+            recon = torch.empty((0, 3, 224, 224), dtype=x.dtype, device=x.device) if want_recon else None
+            return torch.empty((0, 2), dtype=torch.float32, device=x.device), recon
         if eps is None:
             eps = torch.randn((B, self.latent_dims), dtype=torch.float32, device=x.device, generator=self._generator)
         else:

@@ -130,6 +130,17 @@ def test_batch_of_one_and_ragged_batches(sd_ed):
     assert (full - cpu_ref.ed_forward(sd_ed, x)).abs().max().item() <= FP32_TOL
 
 
+def test_empty_batch_gives_empty_logits():
+    """The reference's nn.Modules accept a (0,3,224,224) batch; pred_vid never sends one (`len(df) >= 1`)."""
+    x = torch.zeros((0, 3, 224, 224))
+    assert ed_model()(x.cuda()).shape == (0, 2)
+    lo, rec = vae_model()(x.cuda())
+    assert lo.shape == (0, 2) and rec.shape == (0, 3, 224, 224)
+    g = GenConViT.from_modules(ed_model(), vae_model(), net="genconvit")
+    assert g(x.cuda()).shape == (0, 2)
+    assert pred_func.pred_vids([x, synth.make_frames(2, name="e")], g)[0] is None
+
+
 def test_shards_reassemble_to_unsharded_result(golden):
     """§8e: 8 shards run one after the other on one GPU == the unsharded (2B,2) tensor."""
     from genconvit_amd import dist as gdist
