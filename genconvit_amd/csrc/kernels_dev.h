@@ -211,17 +211,9 @@ dwconv7_ln_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*[49][
   }
 }
 
-// ------------------------------------------------------------------ K4 v2 (16-bit, C = 96 / 192)
-// Same math as dwconv7_ln_kernel, restructured around the memory system:
-//   1. the 13x13 halo window of the tile (all C channels) is staged in LDS with 16-byte coalesced
-//      global loads (21 independent loads per thread in flight, zero fill outside the image) instead
-//      of 169 dependent 2-byte loads per thread
-//   2. a thread still owns one channel of a 7x7 tile with taps + accumulators in registers; inputs
-//      come from LDS (lanes = consecutive channels, conflict-free).  DOT2: horizontally adjacent
-//      inputs are packed in pairs and multiplied with packed tap pairs by v_dot2c_f32_{f16,bf16}
-//      (2 MACs per instruction, fp32 accumulate; the taps are rounded to the storage dtype)
-//   3. LayerNorm statistics through LDS as before; the normalised tile is staged in LDS and written
-//      with 16-byte coalesced stores
+// ------------------------------------------------------------------ K4 (16-bit): packed-pair helpers
+// horizontally adjacent inputs / taps are packed in pairs and multiplied by v_dot2c_f32_{f16,bf16} (2 MACs per
+// instruction, fp32 accumulate; taps rounded to the storage dtype)
 template <typename T> struct Dot2;
 template <> struct Dot2<half_t> {
   typedef _Float16 v2 __attribute__((ext_vector_type(2)));
@@ -244,206 +236,6 @@ template <typename T> __device__ __forceinline__ float from_bits16(uint32_t u) {
   return to_f(__builtin_bit_cast(T, (unsigned short)u));
 }
 
-template <typename T, int C, bool DOT2>
-__global__ void __launch_bounds__(192) dwconv7_ln_v2_kernel(const T* __restrict__ x, const float* __restrict__ wdw,
-                                                            const float* __restrict__ bdw,
-                                                            const float* __restrict__ lnw,
-                                                            const float* __restrict__ lnb, T* __restrict__ y,
-                                                            int nimg, int H, int W, float eps) {
-  static_assert(sizeof(T) == 2 && (C == 96 || C == 192), "v2 covers 16-bit storage, C = 96 / 192");
-  constexpr int TILES = 192 / C;
-  constexpr int NP = TILES * 49;
-  constexpr int CP = C / 8;                           // 16-byte pieces per pixel
-  constexpr int NPIECE = TILES * 169 * CP;            // 4056
-  constexpr int IN_BYTES = TILES * 169 * C * 2;       // 64896
-  constexpr int SVAL_BYTES = NP * C * 4;              // 37632
-  constexpr int STAT_OFF = SVAL_BYTES;                // [NP][2] floats
-  constexpr int OUT_OFF = (STAT_OFF + NP * 8 + 255) & ~255;
-  static_assert(OUT_OFF + NP * C * 2 <= IN_BYTES, "LDS regions must fit in the input window");
-  extern __shared__ __attribute__((aligned(16))) unsigned char dw2_lds[];
-  unsigned short* sIn = reinterpret_cast<unsigned short*>(dw2_lds);
-  float* sval = reinterpret_cast<float*>(dw2_lds);
-  float* stats = reinterpret_cast<float*>(dw2_lds + STAT_OFF);
-  unsigned short* sOut = reinterpret_cast<unsigned short*>(dw2_lds + OUT_OFF);
-
-  const int tid = threadIdx.x;
-  const int tiles_x = (W + 6) / 7, tiles_y = (H + 6) / 7;
-  const int total = nimg * tiles_x * tiles_y;
-  const int tile0 = xcd_remap(blockIdx.x, gridDim.x) * TILES;   // contiguous tile runs per XCD (halo reuse in L2)
-
-  // ---- 1. stage the halo windows -----------------------------------------------------------
-  // batches of independent loads first, LDS stores after: a load->store loop would expose the full
-  // memory latency once per piece (hipcc does not pipeline it)
-  constexpr int NIT = (NPIECE + 191) / 192;            // 22
-  constexpr int BATCH = 11;
-  // per-slot tile origin (the runtime divisions happen once per slot, not once per piece)
-  int s_y0[TILES], s_x0[TILES];
-  int64_t s_img[TILES];
-  bool s_ok[TILES];
-#pragma unroll
-  for (int sl = 0; sl < TILES; ++sl) {
-    const int tl = tile0 + sl;
-    s_ok[sl] = tl < total;
-    const int tlc = s_ok[sl] ? tl : 0;
-    const int txx = tlc % tiles_x, t3 = tlc / tiles_x;
-    s_x0[sl] = txx * 7 - 3;
-    s_y0[sl] = (t3 % tiles_y) * 7 - 3;
-    s_img[sl] = (int64_t)(t3 / tiles_y) * H * W;
-  }
-  // 192 threads = STEP whole pixels per sweep, so a thread keeps its 16-byte column (pc) and walks the
-  // halo pixels with constant stride: (slot, row, col) are updated incrementally, no divisions.
-  constexpr int STEP = 192 / CP;                       // pixels advanced per sweep (16 or 8)
-  const int pc8 = (tid % CP) * 8;
-  int t1 = tid / CP;                                   // slot*169 + pix
-  int slot = 0, r = t1 / 13, sx = t1 - r * 13;         // t1 < 24 < 169 at start
-#pragma unroll 1
-  for (int b0 = 0; b0 < NIT; b0 += BATCH) {
-    u32x4 v[BATCH];
-    int dst[BATCH];
-#pragma unroll
-    for (int i = 0; i < BATCH; ++i) {
-      const bool in_range = t1 < TILES * 169;
-      const int sl = (TILES == 2) ? slot : 0;
-      const int iy = s_y0[sl] + r, ix = s_x0[sl] + sx;
-      const bool ok = in_range && s_ok[sl] && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      dst[i] = in_range ? (t1 * C + pc8) : -1;
-      const int64_t off = ok ? ((s_img[sl] + (int64_t)iy * W + ix) * C + pc8) : 0;   // always a valid address
-      const u32x4 t = *(const u32x4*)(x + off);
-      const uint32_t m = ok ? 0xffffffffu : 0u;
-      v[i] = u32x4{t[0] & m, t[1] & m, t[2] & m, t[3] & m};
-      // advance STEP pixels: 16 = 13 + 3 (or 8)
-      t1 += STEP;
-      sx += STEP % 13;
-      r += STEP / 13;
-      if (sx >= 13) { sx -= 13; r += 1; }
-      if (TILES == 2 && slot == 0 && r >= 13) { r -= 13; slot = 1; }
-    }
-#pragma unroll
-    for (int i = 0; i < BATCH; ++i)
-      if (dst[i] >= 0) *(u32x4*)(sIn + dst[i]) = v[i];
-  }
-
-  const int tslot = tid / C;
-  const int c = tid - tslot * C;
-  const int tile = tile0 + tslot;
-  const bool tile_ok = tile < total;
-  const int tx = tile % tiles_x, t2 = tile / tiles_x;
-  const int ty = t2 % tiles_y, b = t2 / tiles_y;
-  const int x0 = tx * 7, y0 = ty * 7;
-
-  float acc[49];
-  const float bv = bdw[c];
-#pragma unroll
-  for (int t = 0; t < 49; ++t) acc[t] = bv;
-  __syncthreads();
-
-  // ---- 2. 7x7 depthwise taps ------------------------------------------------------------------
-  const unsigned short* sin_c = sIn + tslot * 169 * C + c;
-  if (DOT2) {
-    uint32_t w2[28];                                   // [ky][j] = (tap(ky,2j), tap(ky,2j+1)), tap(ky,7) = 0
-#pragma unroll
-    for (int ky = 0; ky < 7; ++ky)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t lo = bits16<T>(wdw[(ky * 7 + 2 * j) * C + c]);
-        const uint32_t hi = (j < 3) ? bits16<T>(wdw[(ky * 7 + 2 * j + 1) * C + c]) : 0u;
-        w2[ky * 4 + j] = lo | (hi << 16);
-      }
-#pragma unroll
-    for (int r = 0; r < 13; ++r) {
-      uint32_t raw[14];
-#pragma unroll
-      for (int s = 0; s < 13; ++s) raw[s] = sin_c[(r * 13 + s) * C];
-      raw[13] = 0u;
-      uint32_t pp[13];
-#pragma unroll
-      for (int s = 0; s < 13; ++s) pp[s] = raw[s] | (raw[s + 1] << 16);
-#pragma unroll
-      for (int ky = 0; ky < 7; ++ky) {
-        const int oy = r - ky;
-        if (oy >= 0 && oy < 7) {
-#pragma unroll
-          for (int ox = 0; ox < 7; ++ox)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[oy * 7 + ox] = Dot2<T>::run(pp[ox + 2 * j], w2[ky * 4 + j], acc[oy * 7 + ox]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else {
-    float w[49];
-#pragma unroll
-    for (int t = 0; t < 49; ++t) w[t] = wdw[t * C + c];
-#pragma unroll
-    for (int r = 0; r < 13; ++r) {
-      float v[13];
-#pragma unroll
-      for (int s = 0; s < 13; ++s) v[s] = from_bits16<T>(sin_c[(r * 13 + s) * C]);
-#pragma unroll
-      for (int ky = 0; ky < 7; ++ky)
-#pragma unroll
-        for (int sx = 0; sx < 13; ++sx)
-#pragma unroll
-          for (int kx = 0; kx < 7; ++kx) {
-            const int oy = r - ky, ox = sx - kx;
-            if (oy >= 0 && oy < 7 && ox >= 0 && ox < 7)
-              acc[oy * 7 + ox] = fmaf(v[sx], w[ky * 7 + kx], acc[oy * 7 + ox]);
-          }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  __syncthreads();                      // everyone is done reading the input window: reuse it
-
-  // ---- 3. LayerNorm over channels ------------------------------------------------------------
-#pragma unroll
-  for (int p = 0; p < 49; ++p) sval[(tslot * 49 + p) * C + c] = acc[p];
-  __syncthreads();
-  const int grp = tid >> 5, gl = tid & 31;
-  for (int p = grp; p < NP; p += 6) {
-    const float* row = sval + p * C;
-    float s = 0.0f;
-#pragma unroll
-    for (int k = 0; k < C / 32; ++k) s += row[gl + 32 * k];
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    const float mean = s * (1.0f / C);
-    float q = 0.0f;
-#pragma unroll
-    for (int k = 0; k < C / 32; ++k) { const float d = row[gl + 32 * k] - mean; q = fmaf(d, d, q); }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-    if (gl == 0) {
-      stats[2 * p] = mean;
-      stats[2 * p + 1] = 1.0f / sqrtf(q * (1.0f / C) + eps);
-    }
-  }
-  __syncthreads();
-  {
-    const float lw = lnw[c], lb = lnb[c];
-#pragma unroll
-    for (int p = 0; p < 49; ++p) {
-      const float mean = stats[2 * (tslot * 49 + p)], rstd = stats[2 * (tslot * 49 + p) + 1];
-      sOut[(tslot * 49 + p) * C + c] = (unsigned short)bits16<T>((acc[p] - mean) * rstd * lw + lb);
-    }
-  }
-  __syncthreads();
-  {
-    int q1 = tid / CP;                                 // slot*49 + p
-    int oslot = 0, orow = q1 / 7, ocol = q1 - orow * 7;   // q1 < 24 < 49 at start
-#pragma unroll 1
-    for (; q1 < NP; q1 += STEP) {
-      const int sl = (TILES == 2) ? oslot : 0;
-      const int oy = s_y0[sl] + 3 + orow, ox = s_x0[sl] + 3 + ocol;
-      if (s_ok[sl] && oy < H && ox < W)
-        *(u32x4*)(y + ((s_img[sl] + (int64_t)oy * W + ox) * C + pc8)) = *(const u32x4*)(sOut + q1 * C + pc8);
-      ocol += STEP % 7;
-      orow += STEP / 7;
-      if (ocol >= 7) { ocol -= 7; orow += 1; }
-      if (TILES == 2 && oslot == 0 && orow >= 7) { orow -= 7; oslot = 1; }
-    }
-  }
-}
-
 // taps (49, C) fp32 -> [28][C] dwords of packed 16-bit pairs (tap(ky,2j), tap(ky,2j+1)), tap(ky,7) = 0: the LDS image
 // the v3 kernel works from.  Built once when the weights are loaded (per tile it cost 11 % of the C=96 kernel).
 template <typename T>
@@ -461,12 +253,14 @@ __global__ void __launch_bounds__(256) pack_dw_taps_kernel(const float* __restri
 #define GCV_DW_ABLATE 0     // diagnostics: 1 one tap row, 2 no LN stats, 4 no tap packing, 8 no halo loads, 16 no stores
 #endif
 // ------------------------------------------------------------------ K4 v3 (16-bit, C = 96 / 192)
-// Occupancy-first decomposition of the same op: one workgroup = one 7x7 tile, one THREAD = one channel
-// of RPT output rows (7 x RPT accumulators), i.e. 672 (C=96) / 768 (C=192) threads per tile instead of
-// 96 / 192.  The per-tile costs (halo staging, LayerNorm statistics, coalesced store) are spread over
-// 7x / 4x more threads, a thread needs ~60 VGPRs, and the CU holds ~32 waves, so the LDS / memory
-// waits of one wave are covered by the others (v2: 6 waves per CU, 43 % of wave time in s_waitcnt).
-// Taps live in LDS as packed pairs [28][C]; inputs in LDS [13x13][C]; MACs by v_dot2c (fp32 accumulate).
+// Occupancy-first decomposition of the same op: one workgroup = one 7x7 tile, one THREAD = one channel of RPT
+// output rows (7 x RPT accumulators): 384 threads per tile at C = 96 (RPT = 2, three workgroups per CU), 768 at
+// C = 192 (two per CU), instead of one thread per channel with 49 accumulators.  The 13x13 halo window (all C
+// channels) is staged in LDS by 16-byte coalesced loads (zero fill outside the image); taps live in LDS as packed
+// pairs [28][C], pre-packed at weight-load time (`wpk`; packing them per tile cost 11 % of the kernel); MACs by
+// v_dot2c (fp32 accumulate); LayerNorm statistics by 32-lane group reductions over an LDS [pixel][C] image; the
+// normalised tile is written with 16-byte stores.  Phase costs at C = 96, 256 images (GCV_DW_ABLATE builds): taps +
+// LN 163 us, halo loads 45, tap packing 37 (gone with wpk), stores 9, launch / barrier skeleton 82 of 335.
 template <typename T, int C, int RPT, bool DOT2>
 __global__ void __launch_bounds__(((7 + RPT - 1) / RPT) * C)
 dwconv7_ln_v3_kernel(const T* __restrict__ x, const float* __restrict__ wdw, const float* __restrict__ bdw,
@@ -659,295 +453,6 @@ dwconv7_ln_v3_kernel(const T* __restrict__ x, const float* __restrict__ wdw, con
     const int p = idx / CP, pc = idx - p * CP;
     const int oy = y0 + p / 7, ox = x0 + p % 7;
     if (oy < H && ox < W && (!(GCV_DW_ABLATE & 16) || sOut[p * C + 8 * pc] == 0x1234)) *(u32x4*)(y + ((img + (int64_t)oy * W + ox) * C + 8 * pc)) = *(const u32x4*)(sOut + p * C + 8 * pc);
-  }
-}
-
-// ------------------------------------------------------------------ K4 v5 (16-bit, C = 96): two channels per thread
-// Same tile decomposition as v3 (one workgroup = one 7x7 tile, LDS halo [13x13][C], taps as packed pairs), but a
-// thread owns a channel PAIR of one output row: every LDS access moves 4 or 8 bytes instead of 2 or 4 (half the LDS
-// instructions per output), the workgroup is 336 threads = 6 waves instead of 11, and three workgroups share a CU
-// (18 waves, 130 KB LDS) instead of two — the five barriers of a tile then have two other tiles to hide behind.
-template <typename T, int C>
-__global__ void __launch_bounds__(7 * C / 2, 5)
-dwconv7_ln_v5_kernel(const T* __restrict__ x, const float* __restrict__ wdw, const float* __restrict__ bdw,
-                     const float* __restrict__ lnw, const float* __restrict__ lnb, T* __restrict__ y, int nimg, int H,
-                     int W, float eps) {
-  static_assert(sizeof(T) == 2 && C == 96, "v5 covers 16-bit storage, C = 96");
-  constexpr int HP = C / 2;                           // channel pairs
-  constexpr int NT = 7 * HP;                          // 336 threads
-  constexpr int CP = C / 8;                           // 16-byte pieces per pixel
-  constexpr int IN_BYTES = 169 * C * 2;
-  constexpr int STAT_OFF = 49 * C * 4;
-  constexpr int OUT_OFF = (STAT_OFF + 49 * 8 + 255) & ~255;
-  static_assert(OUT_OFF + 49 * C * 2 <= IN_BYTES, "LN / output staging must fit in the halo window");
-  extern __shared__ __attribute__((aligned(16))) unsigned char dw5_lds[];
-  unsigned short* sIn = reinterpret_cast<unsigned short*>(dw5_lds);
-  float* sval = reinterpret_cast<float*>(dw5_lds);
-  float* stats = reinterpret_cast<float*>(dw5_lds + STAT_OFF);
-  unsigned short* sOut = reinterpret_cast<unsigned short*>(dw5_lds + OUT_OFF);
-  uint32_t* sW2 = reinterpret_cast<uint32_t*>(dw5_lds + IN_BYTES);     // [28][C] packed tap pairs
-
-  const int tid = threadIdx.x;
-  const int tiles_x = (W + 6) / 7, tiles_y = (H + 6) / 7;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tx = tile % tiles_x, t2 = tile / tiles_x;
-  const int ty = t2 % tiles_y, b = t2 / tiles_y;
-  const int x0 = tx * 7, y0 = ty * 7;
-  const int64_t img = (int64_t)b * H * W;
-
-  for (int i = tid; i < 28 * C; i += NT) {
-    const int c = i % C, kj = i / C;
-    const int ky = kj >> 2, j = kj & 3;
-    const uint32_t lo = bits16<T>(wdw[(ky * 7 + 2 * j) * C + c]);
-    const uint32_t hi = (j < 3) ? bits16<T>(wdw[(ky * 7 + 2 * j + 1) * C + c]) : 0u;
-    sW2[i] = lo | (hi << 16);
-  }
-  constexpr int NPIECE = 169 * CP;
-  constexpr int NIT = (NPIECE + NT - 1) / NT;
-  {
-    u32x4 v[NIT];
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int idx = tid + i * NT;
-      const int pix = idx / CP, pc = idx - pix * CP;
-      const int r = pix / 13, sx = pix - r * 13;
-      const int iy = y0 + r - 3, ix = x0 + sx - 3;
-      const bool ok = idx < NPIECE && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      const int64_t off = ok ? ((img + (int64_t)iy * W + ix) * C + 8 * pc) : 0;
-      const u32x4 t = *(const u32x4*)(x + off);
-      const uint32_t m = ok ? 0xffffffffu : 0u;
-      v[i] = u32x4{t[0] & m, t[1] & m, t[2] & m, t[3] & m};
-    }
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int idx = tid + i * NT;
-      if (idx < NPIECE) *(u32x4*)(sIn + idx * 8) = v[i];
-    }
-  }
-  __syncthreads();
-
-  const int rg = tid / HP, cp = tid - rg * HP;          // output row, channel pair
-  const int c0 = 2 * cp;
-  float acc[2][7];
-  {
-    const float2 bv = *(const float2*)(bdw + c0);
-#pragma unroll
-    for (int ox = 0; ox < 7; ++ox) { acc[0][ox] = bv.x; acc[1][ox] = bv.y; }
-  }
-  const uint32_t* sIn32 = reinterpret_cast<const uint32_t*>(sIn);
-#pragma unroll
-  for (int ky = 0; ky < 7; ++ky) {
-    const int r = rg + ky;
-    uint2 w2[4];                                        // taps (ky, 2j..2j+1) of both channels
-#pragma unroll
-    for (int j = 0; j < 4; ++j) w2[j] = *(const uint2*)(sW2 + (ky * 4 + j) * C + c0);
-    uint32_t raw[14];                                   // (x[c0], x[c1]) at window column s
-#pragma unroll
-    for (int s = 0; s < 13; ++s) raw[s] = sIn32[((r * 13 + s) * C + c0) >> 1];
-    raw[13] = 0u;
-#pragma unroll
-    for (int ox = 0; ox < 7; ++ox) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int s = ox + 2 * j;
-        const uint32_t p0 = __builtin_amdgcn_perm(raw[s + 1], raw[s], 0x05040100u);   // (x_c0[s], x_c0[s+1])
-        const uint32_t p1 = __builtin_amdgcn_perm(raw[s + 1], raw[s], 0x07060302u);   // (x_c1[s], x_c1[s+1])
-        acc[0][ox] = Dot2<T>::run(p0, w2[j].x, acc[0][ox]);
-        acc[1][ox] = Dot2<T>::run(p1, w2[j].y, acc[1][ox]);
-      }
-    }
-  }
-  __syncthreads();                                     // halo window is free: reuse it for LayerNorm
-#pragma unroll
-  for (int ox = 0; ox < 7; ++ox) *(float2*)(sval + (rg * 7 + ox) * C + c0) = make_float2(acc[0][ox], acc[1][ox]);
-  __syncthreads();
-  {
-    const int grp = tid >> 5, gl = tid & 31;
-    for (int p = grp; p < 49 && grp < NT / 32; p += NT / 32) {
-      const float* row = sval + p * C;
-      float s = 0.0f;
-#pragma unroll
-      for (int k = 0; k < C / 32; ++k) s += row[gl + 32 * k];
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-      const float mean = s * (1.0f / C);
-      float q = 0.0f;
-#pragma unroll
-      for (int k = 0; k < C / 32; ++k) { const float d = row[gl + 32 * k] - mean; q = fmaf(d, d, q); }
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-      if (gl == 0) {
-        stats[2 * p] = mean;
-        stats[2 * p + 1] = 1.0f / sqrtf(q * (1.0f / C) + eps);
-      }
-    }
-  }
-  __syncthreads();
-  {
-    const float2 lw = *(const float2*)(lnw + c0), lb = *(const float2*)(lnb + c0);
-    uint32_t* sOut32 = reinterpret_cast<uint32_t*>(sOut);
-#pragma unroll
-    for (int ox = 0; ox < 7; ++ox) {
-      const int p = rg * 7 + ox;
-      const float2 st = *(const float2*)(stats + 2 * p);
-      const uint32_t lo = bits16<T>((acc[0][ox] - st.x) * st.y * lw.x + lb.x);
-      const uint32_t hi = bits16<T>((acc[1][ox] - st.x) * st.y * lw.y + lb.y);
-      sOut32[(p * C + c0) >> 1] = lo | (hi << 16);
-    }
-  }
-  __syncthreads();
-  for (int idx = tid; idx < 49 * CP; idx += NT) {
-    const int p = idx / CP, pc = idx - p * CP;
-    const int oy = y0 + p / 7, ox = x0 + p % 7;
-    if (oy < H && ox < W) *(u32x4*)(y + ((img + (int64_t)oy * W + ox) * C + 8 * pc)) = *(const u32x4*)(sOut + p * C + 8 * pc);
-  }
-}
-
-// workgroup barrier for LDS traffic only.  __syncthreads() is fence + barrier: the fence waits for vmcnt(0), i.e. for
-// every global load and store the wave has in flight — exactly what a software-pipelined kernel must not do.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// ------------------------------------------------------------------ K4 v4 (16-bit, C = 96): v3 + tile pipelining
-// One workgroup walks TPW consecutive 7x7 tiles (a tile row of the image).  The halo window of tile t+1 is fetched
-// into registers (4 x 16 B per thread) right after tile t's window has been handed to LDS, so the global / L2 latency
-// of the halo (the largest single wait of v3: ~3 us of a ~10 us tile) runs under the taps, LayerNorm and store of
-// tile t.  Taps are packed into LDS once per workgroup instead of once per tile.  __launch_bounds__(.., 6) keeps the
-// kernel at <= 80 VGPRs so two 11-wave workgroups still share a CU.
-template <typename T, int C, int TPW>
-__global__ void __launch_bounds__(7 * C, 6)
-dwconv7_ln_v4_kernel(const T* __restrict__ x, const float* __restrict__ wdw, const float* __restrict__ bdw,
-                     const float* __restrict__ lnw, const float* __restrict__ lnb, T* __restrict__ y, int nimg, int H,
-                     int W, float eps) {
-  static_assert(sizeof(T) == 2 && C == 96, "v4 covers 16-bit storage, C = 96");
-  constexpr int NT = 7 * C;
-  constexpr int CP = C / 8;                           // 16-byte pieces per pixel
-  constexpr int IN_BYTES = 169 * C * 2;
-  constexpr int STAT_OFF = 49 * C * 4;
-  constexpr int OUT_OFF = (STAT_OFF + 49 * 8 + 255) & ~255;
-  static_assert(OUT_OFF + 49 * C * 2 <= IN_BYTES, "LN / output staging must fit in the halo window");
-  extern __shared__ __attribute__((aligned(16))) unsigned char dw4_lds[];
-  unsigned short* sIn = reinterpret_cast<unsigned short*>(dw4_lds);
-  float* sval = reinterpret_cast<float*>(dw4_lds);
-  float* stats = reinterpret_cast<float*>(dw4_lds + STAT_OFF);
-  unsigned short* sOut = reinterpret_cast<unsigned short*>(dw4_lds + OUT_OFF);
-  uint32_t* sW2 = reinterpret_cast<uint32_t*>(dw4_lds + IN_BYTES);     // [28][C] packed tap pairs
-
-  const int tid = threadIdx.x;
-  const int tiles_x = (W + 6) / 7, tiles_y = (H + 6) / 7;
-  const int ntiles = nimg * tiles_x * tiles_y;
-  const int tile0 = xcd_remap(blockIdx.x, gridDim.x) * TPW;
-
-  for (int i = tid; i < 28 * C; i += NT) {
-    const int c = i % C, kj = i / C;
-    const int ky = kj >> 2, j = kj & 3;
-    const uint32_t lo = bits16<T>(wdw[(ky * 7 + 2 * j) * C + c]);
-    const uint32_t hi = (j < 3) ? bits16<T>(wdw[(ky * 7 + 2 * j + 1) * C + c]) : 0u;
-    sW2[i] = lo | (hi << 16);
-  }
-  const int rg = tid / C, c = tid - rg * C;             // output row of the tile, channel
-  const float bv = bdw[c], lw = lnw[c], lb = lnb[c];
-
-  constexpr int NPIECE = 169 * CP;
-  constexpr int NIT = (NPIECE + NT - 1) / NT;
-  u32x4 v[NIT];
-  auto fetch = [&](int tile) {
-    const int tx = tile % tiles_x, t2 = tile / tiles_x;
-    const int ty = t2 % tiles_y, b = t2 / tiles_y;
-    const int x0 = tx * 7, y0 = ty * 7;
-    const int64_t img = (int64_t)b * H * W;
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int idx = tid + i * NT;
-      const int pix = idx / CP, pc = idx - pix * CP;
-      const int r = pix / 13, sx = pix - r * 13;
-      const int iy = y0 + r - 3, ix = x0 + sx - 3;
-      const bool ok = idx < NPIECE && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      const int64_t off = ok ? ((img + (int64_t)iy * W + ix) * C + 8 * pc) : 0;
-      const u32x4 t = *(const u32x4*)(x + off);
-      const uint32_t m = ok ? 0xffffffffu : 0u;
-      v[i] = u32x4{t[0] & m, t[1] & m, t[2] & m, t[3] & m};
-    }
-  };
-  if (tile0 < ntiles) fetch(tile0);
-
-#pragma unroll 1
-  for (int t = 0; t < TPW; ++t) {
-    const int tile = tile0 + t;
-    if (tile >= ntiles) break;                         // uniform over the workgroup
-    const int tx = tile % tiles_x, t2 = tile / tiles_x;
-    const int ty = t2 % tiles_y, b = t2 / tiles_y;
-    const int x0 = tx * 7, y0 = ty * 7;
-    const int64_t img = (int64_t)b * H * W;
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int idx = tid + i * NT;
-      if (idx < NPIECE) *(u32x4*)(sIn + idx * 8) = v[i];
-    }
-    lds_barrier();
-    if (t + 1 < TPW && tile + 1 < ntiles) fetch(tile + 1);   // in flight until the next iteration's LDS write
-
-    float acc[7];
-#pragma unroll
-    for (int ox = 0; ox < 7; ++ox) acc[ox] = bv;
-    {
-#pragma unroll
-      for (int ky = 0; ky < 7; ++ky) {
-        __builtin_amdgcn_sched_barrier(0);               // one kernel row at a time: bounds the LDS reads in flight (VGPRs)
-        const int r = rg + ky;
-        uint32_t w2[4];                                  // this kernel row's tap pairs (kept out of the loop-carried set)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w2[j] = sW2[(ky * 4 + j) * C + c];
-        uint32_t raw[14];
-#pragma unroll
-        for (int s = 0; s < 13; ++s) raw[s] = sIn[(r * 13 + s) * C + c];
-        raw[13] = 0u;
-        uint32_t pp[13];
-#pragma unroll
-        for (int s = 0; s < 13; ++s) pp[s] = raw[s] | (raw[s + 1] << 16);
-#pragma unroll
-        for (int ox = 0; ox < 7; ++ox)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[ox] = Dot2<T>::run(pp[ox + 2 * j], w2[j], acc[ox]);
-      }
-    }
-    lds_barrier();                                     // halo window is free: reuse it for LayerNorm
-#pragma unroll
-    for (int ox = 0; ox < 7; ++ox) sval[(rg * 7 + ox) * C + c] = acc[ox];
-    lds_barrier();
-    {
-      const int grp = tid >> 5, gl = tid & 31;
-      for (int p = grp; p < 49; p += NT / 32) {
-        const float* row = sval + p * C;
-        float s = 0.0f;
-#pragma unroll
-        for (int k = 0; k < C / 32; ++k) s += row[gl + 32 * k];
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        const float mean = s * (1.0f / C);
-        float q = 0.0f;
-#pragma unroll
-        for (int k = 0; k < C / 32; ++k) { const float d = row[gl + 32 * k] - mean; q = fmaf(d, d, q); }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-        if (gl == 0) {
-          stats[2 * p] = mean;
-          stats[2 * p + 1] = 1.0f / sqrtf(q * (1.0f / C) + eps);
-        }
-      }
-    }
-    lds_barrier();
-#pragma unroll
-    for (int ox = 0; ox < 7; ++ox) {
-      const int p = rg * 7 + ox;
-      sOut[p * C + c] = (unsigned short)bits16<T>((acc[ox] - stats[2 * p]) * stats[2 * p + 1] * lw + lb);
-    }
-    lds_barrier();
-    for (int idx = tid; idx < 49 * CP; idx += NT) {
-      const int p = idx / CP, pc = idx - p * CP;
-      const int oy = y0 + p / 7, ox = x0 + p % 7;
-      if (oy < H && ox < W) *(u32x4*)(y + ((img + (int64_t)oy * W + ox) * C + 8 * pc)) = *(const u32x4*)(sOut + p * C + 8 * pc);
-    }
-    lds_barrier();                                     // staging is read out: the next halo may overwrite it
   }
 }
 

@@ -38,24 +38,6 @@ static int launch_dw_c(const T* x, const float* wdw, const float* bdw, const flo
   return 0;
 }
 
-template <typename T, int C, bool DOT2>
-static int launch_dw_v2(const T* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb, T* y,
-                        int nimg, int H, int W, float eps, hipStream_t s) {
-  constexpr int TILES = 192 / C;
-  constexpr int LDS = TILES * 169 * C * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    GCV_CHECK_HIP(hipFuncSetAttribute((const void*)dwconv7_ln_v2_kernel<T, C, DOT2>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
-  const int tiles = nimg * cdiv(H, 7) * cdiv(W, 7);
-  hipLaunchKernelGGL((dwconv7_ln_v2_kernel<T, C, DOT2>), dim3(cdiv(tiles, TILES)), dim3(192), LDS, s, x, wdw, bdw, lnw,
-                     lnb, y, nimg, H, W, eps);
-  GCV_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
 template <typename T, int C, int RPT, bool DOT2>
 static int launch_dw_v3(const T* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb, T* y,
                         int nimg, int H, int W, float eps, hipStream_t s, const uint32_t* wpk) {
@@ -75,30 +57,8 @@ static int launch_dw_v3(const T* x, const float* wdw, const float* bdw, const fl
   return 0;
 }
 
-template <typename T, int C, int TPW>
-static int launch_dw_v4(const T* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb, T* y,
-                        int nimg, int H, int W, float eps, hipStream_t s) {
-  constexpr int LDS = 169 * C * 2 + 28 * C * 4;
-  const int tiles = nimg * cdiv(H, 7) * cdiv(W, 7);
-  hipLaunchKernelGGL((dwconv7_ln_v4_kernel<T, C, TPW>), dim3(cdiv(tiles, TPW)), dim3(7 * C), LDS, s, x, wdw, bdw, lnw, lnb,
-                     y, nimg, H, W, eps);
-  GCV_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
-template <typename T, int C>
-static int launch_dw_v5(const T* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb, T* y,
-                        int nimg, int H, int W, float eps, hipStream_t s) {
-  constexpr int LDS = 169 * C * 2 + 28 * C * 4;
-  const int tiles = nimg * cdiv(H, 7) * cdiv(W, 7);
-  hipLaunchKernelGGL((dwconv7_ln_v5_kernel<T, C>), dim3(tiles), dim3(7 * C / 2), LDS, s, x, wdw, bdw, lnw, lnb, y, nimg, H, W,
-                     eps);
-  GCV_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
-// 7: v5 (two channels per thread, C = 96), 5: v4 (tile-pipelined v3, C = 96), 0: v3 + dot2 (default for 16-bit C<=192), 4: v3 with fp32 FMA taps, 1: v2 + dot2, 2: v1 everywhere,
-// 3: v2 with fp32 FMA taps (env GCV_DWCONV_MODE, A/B switch for profiling)
+// GCV_DWCONV_MODE (A/B switch for profiling): 0 = v3 with packed-pair dot2 taps (default for 16-bit, C <= 192),
+// 1 = v3 with one output row per thread at C = 96, 2 = the generic kernel everywhere, 4 = v3 with fp32 FMA taps
 static inline int dwconv_mode() {
   static const int mode = [] { const char* e = std::getenv("GCV_DWCONV_MODE"); return e ? std::atoi(e) : 0; }();
   return mode;
@@ -122,20 +82,14 @@ int launch_dwconv7_ln(const T* x, const float* wdw, const float* bdw, const floa
     const int mode = dwconv_mode();
     if (mode != 2 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0) {
       if (C == 96) {
-        if (mode == 8) return launch_dw_v3<T, 96, 1, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
-        if (mode == 7) return launch_dw_v5<T, 96>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
-        if (mode == 5) return launch_dw_v4<T, 96, 8>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
-        if (mode == 6) return launch_dw_v4<T, 96, 4>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
-        if (mode == 0) return launch_dw_v3<T, 96, 2, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);   // two rows per thread: 384 threads, 3 workgroups per CU
-        if (mode == 4) return launch_dw_v3<T, 96, 1, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
-        return mode == 1 ? launch_dw_v2<T, 96, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s)
-                         : launch_dw_v2<T, 96, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
+        // two output rows per thread: 384 threads, three workgroups per CU
+        if (mode == 0) return launch_dw_v3<T, 96, 2, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
+        if (mode == 1) return launch_dw_v3<T, 96, 1, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
+        if (mode == 4) return launch_dw_v3<T, 96, 2, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
       }
       if (C == 192) {
-        if (mode == 0) return launch_dw_v3<T, 192, 2, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
+        if (mode == 0 || mode == 1) return launch_dw_v3<T, 192, 2, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
         if (mode == 4) return launch_dw_v3<T, 192, 2, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
-        return mode == 1 ? launch_dw_v2<T, 192, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s)
-                         : launch_dw_v2<T, 192, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
       }
     }
   }
