@@ -4,14 +4,15 @@
 
 #include "fused_mlp.h"
 #include "fused_mlp_res.h"
+#include "fused_mlp_c384.h"
 
 namespace gcv {
 
 // W2 (C, 4C) fp32 row-major -> [4C/HC][C][HC] in T; inside every 16 hidden indices bits 2 and 3 are
 // swapped so that a lane's GEMM2 A-operand fragment (k = 16kk + 8(j>>2) + 4h + (j&3)) is one 16-byte chunk.
 template <typename T>
-__global__ void __launch_bounds__(256) pack_w2_chunks_kernel(const float* __restrict__ w2, T* __restrict__ out, int C) {
-  const int HC = kMlpHC;
+__global__ void __launch_bounds__(256) pack_w2_chunks_kernel(const float* __restrict__ w2, T* __restrict__ out, int C,
+                                                             int HC) {
   const int64_t total = (int64_t)C * 4 * C;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
@@ -24,10 +25,14 @@ __global__ void __launch_bounds__(256) pack_w2_chunks_kernel(const float* __rest
   out[i] = from_f<T>(w2[(int64_t)o * 4 * C + ch * HC + hid]);
 }
 
+// chunk width: 96 hidden for the C = 96 / 192 kernels, 32 (one MFMA k-group) for the C = 384 kernel
+static inline int mlp_chunk_width(int C) { return C == 384 ? 32 : kMlpHC; }
+
 template <typename T> int launch_pack_w2_chunks(const float* w2_dev, T* out, int C, hipStream_t s) {
-  GCV_REQUIRE((4 * C) % kMlpHC == 0, "hidden width must be a multiple of the chunk");
+  const int HC = mlp_chunk_width(C);
+  GCV_REQUIRE((4 * C) % HC == 0 && HC % 16 == 0, "hidden width must be a multiple of the chunk");
   const int64_t total = (int64_t)C * 4 * C;
-  hipLaunchKernelGGL((pack_w2_chunks_kernel<T>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, w2_dev, out, C);
+  hipLaunchKernelGGL((pack_w2_chunks_kernel<T>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, w2_dev, out, C, HC);
   GCV_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -59,6 +64,19 @@ template <typename T> int launch_fused_mlp_res(const MlpArgs& a, hipStream_t s) 
   return 0;
 }
 
+template <typename T> int launch_fused_mlp_c384(const MlpArgs& a, hipStream_t s) {
+  constexpr int SMEM = Mlp384Smem::bytes;
+  static bool attr_done = false;
+  if (!attr_done) {
+    GCV_CHECK_HIP(hipFuncSetAttribute((const void*)fused_mlp_c384_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    attr_done = true;
+  }
+  const int ntiles = cdiv(a.M, 128);
+  hipLaunchKernelGGL((fused_mlp_c384_kernel<T>), dim3(ntiles < 256 ? ntiles : 256), dim3(256), SMEM, s, a, ntiles);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 template <typename T> int launch_fused_mlp(const MlpArgs& a, int C, hipStream_t s) {
   GCV_REQUIRE(a.M > 0 && a.X && a.W1 && a.W2c && a.b1 && a.b2 && a.gamma && a.resid && a.out, "fused MLP: null argument");
   // C=96: 4-wave workgroups (81 KB LDS -> two independent workgroups per CU overlap each other's
@@ -68,7 +86,8 @@ template <typename T> int launch_fused_mlp(const MlpArgs& a, int C, hipStream_t 
   if (C == 96 && res_mode && a.M >= 256 * 8 * 32) return launch_fused_mlp_res<T>(a, s);
   if (C == 96) return launch_mlp_c<T, 96, 4>(a, s);
   if (C == 192) return launch_mlp_c<T, 192, 8>(a, s);
-  set_error("fused MLP is built for C = 96 and C = 192");
+  if (C == 384) return launch_fused_mlp_c384<T>(a, s);
+  set_error("fused MLP is built for C = 96, 192 and 384");
   return -3;
 }
 

@@ -232,13 +232,17 @@ __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) 
 
     if (titer == 2) GCV_STAMP(7);
     // ---- epilogue: (acc2 + b2) * gamma + resid -> 16-bit, 8-byte pieces ----
+    // (pointers through an empty asm: keeps the loop-invariant b2 / gamma LDS reads inside the tile loop, unspilled)
+    const float* sB2t = sB2;
+    const float* sGt = sG;
+    asm volatile("" : "+v"(sB2t), "+v"(sGt));
 #pragma unroll
     for (int o = 0; o < NO; ++o)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int n = 32 * o + 8 * q + 4 * lh;
-        const f32x4 bv = *(const f32x4*)(sB2 + n);
-        const f32x4 gv = *(const f32x4*)(sG + n);
+        const f32x4 bv = *(const f32x4*)(sB2t + n);
+        const f32x4 gv = *(const f32x4*)(sGt + n);
         t4 o4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o4[e] = from_f<T>(fmaf(acc2[o][4 * q + e] + bv[e], gv[e], to_f(rres[o][q][e])));

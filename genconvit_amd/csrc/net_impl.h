@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256) pack_mu_kernel(const float* __restrict__ 
 template <typename T> struct CnxBlockW {
   float *dw_w, *dw_b, *ln_w, *ln_b, *fc1_b, *fc2_b, *gamma;
   T *fc1_w, *fc2_w;
-  T* fc2_wc;       // 16-bit, C <= 192: W2 packed for the fused MLP kernel (else null)
+  T* fc2_wc;       // 16-bit, C <= 384: W2 packed for the fused MLP kernels (else null)
   uint32_t* dw_wpk; // 16-bit, C <= 192: dw taps as packed pairs [28][C] for dwconv7_ln_v3_kernel (else null)
 };
 template <typename T> struct CnxW {
@@ -151,7 +151,10 @@ template <typename T> struct NetImpl : NetBase {
   bool has_ed = false, has_vae = false, has_swin = false;
   Arena arena;
   hipStream_t cur = nullptr;
-  bool use_fused_mlp = std::getenv("GCV_NO_FUSED_MLP") == nullptr;   // A/B switch for profiling
+  bool use_fused_mlp = std::getenv("GCV_NO_FUSED_MLP") == nullptr;   // A/B switches for profiling
+  // the C = 384 fused kernel (fused_mlp_c384.h) is correct but measures 309 us against 216 us for pw1 + pw2 at 256
+  // images (one wave per SIMD cannot hide its LDS / MFMA latencies): opt-in for experiments only
+  bool use_fused_mlp384 = std::getenv("GCV_FUSED_MLP384") != nullptr;
 
   ~NetImpl() override {
     if (arena.base) (void)hipFree(arena.base);
@@ -327,7 +330,7 @@ template <typename T> struct NetImpl : NetBase {
         GCV_TRY(up_cast(w, b + "mlp.fc2.weight", (int64_t)4 * C * C, st, k.fc2_w));
         k.fc2_wc = nullptr;
         if constexpr (sizeof(T) == 2) {
-          if (C <= 192) {
+          if (C <= 192 || (C == 384 && use_fused_mlp384)) {   // stages with a fused MLP kernel in use
             std::vector<float> v;
             GCV_TRY(fetch(w, b + "mlp.fc2.weight", (int64_t)4 * C * C, v));
             float* tmp = nullptr;
@@ -536,7 +539,7 @@ template <typename T> struct NetImpl : NetBase {
           }));
         }
         if constexpr (sizeof(T) == 2) {
-          if (k.fc2_wc && use_fused_mlp) {
+          if (k.fc2_wc && use_fused_mlp && (C < 384 || use_fused_mlp384)) {
             MlpArgs ma{Y, k.fc1_w, k.fc1_b, k.fc2_wc, k.fc2_b, k.gamma, X, X, (int)M};
             GCV_TRY(run("cnx.fused_mlp", 16.0 * M * C * (double)C, 3.0 * sizeof(T) * (double)M * C + 16.0 * C * C,
                         [&] { return launch_fused_mlp<T>(ma, C, cur); }));

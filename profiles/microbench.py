@@ -43,7 +43,7 @@ if which.startswith("dwconv"):
     run(fn, 2.0 * 49 * n, 4.0 * n)
 elif which.startswith("mlp"):
     C = int(which[3:])
-    H = {96: 56, 192: 28}[C]
+    H = {96: 56, 192: 28, 384: 14}[C]
     M = nimg * H * H
     x = R(M, C).to(dt)
     res = R(M, C).to(dt)

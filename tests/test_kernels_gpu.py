@@ -395,7 +395,8 @@ def test_mean_over_tokens(dt):
 # ----------------------------------------------------------------------------- fused ConvNeXt MLP
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("C,M", [(96, 256), (96, 1000), (192, 300), (192, 37),
-                                 (96, 70013)])      # >= 65536 tokens at C=96: the LDS-resident persistent kernel
+                                 (96, 70013),       # >= 65536 tokens at C=96: the LDS-resident persistent kernel
+                                 (384, 128), (384, 1000), (384, 40000)])   # C=384: persistent LDS-DMA weight ring (1 tile, ragged, 2 tiles per CU)
 def test_fused_mlp_layerscale_residual(dt, C, M):
     """timm ConvNeXtBlock tail: fc1 -> exact GELU -> fc2 -> * gamma -> + shortcut, hidden kept on chip."""
     dtype = DTYPES[dt]
