@@ -5,9 +5,10 @@
 // flight; at the ConvNeXt stage-2/3 shapes a K tile is ~400 MFMA cycles of work but ~1.8 us of
 // memory latency (the 4C-wide hidden operand streams from HBM), and its 128x96 tile moves 0.018 B of
 // operand per FLOP through L2.  This kernel
-//   * loads operands with LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write) into a ring
-//     of S = 4 K-tile stages and waits with a COUNTED vmcnt, so three stages (60 KB per workgroup,
-//     120 KB per CU) are in flight while one is consumed — one raw s_barrier per K tile
+//   * loads operands with LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write) into a ring of K-tile
+//     stages and waits with a COUNTED vmcnt — one raw s_barrier per K tile.  The fill rate of a CU does not depend on
+//     the ring depth (profiles/micro/lds_dma_rate.hip), only on how many workgroups issue and on the piece size, so
+//     the ring is double-buffered: 64-byte rows 2 x 20 KB (three workgroups per CU), 128-byte rows 2 x 40 KB (two)
 //   * uses a 128 x 192 tile, 4 waves as 2(M) x 2(N), 64 x 96 per wave (2x3 32x32 accumulators):
 //     0.013 B/FLOP from L2 and 0.83 LDS fragment reads per MFMA
 //   * LDS image is lane-linear per DMA instruction (16 rows x 64 B); the bank swizzle is applied to the
@@ -24,7 +25,7 @@ namespace gcv {
 #define GCV_GLDS_ABLATE 0     // diagnostics only: 1 = no MFMA/fragment reads, 2 = no steady-state loads, 4 = no epilogue math
 #endif
 #ifndef GCV_GLDS_STAGES
-#define GCV_GLDS_STAGES 4
+#define GCV_GLDS_STAGES 2     // 64-byte-row ring: 2 x 20 KB leaves room for THREE workgroups per CU (-5 % at K = 384 vs 4 stages)
 #endif
 #ifndef GCV_GLDS_STAMPS
 #define GCV_GLDS_STAMPS 0     // diagnostics only: per-workgroup s_memtime stamps + HW_ID into a side buffer
@@ -43,8 +44,10 @@ __device__ unsigned long long gcv_glds_stamps[4096 * 8];
 #define GLDS_STAMP(i) do { } while (0)
 #endif
 constexpr int kGldsBM = 128, kGldsBN = 192;
-// ring geometry by bytes per LDS row: 64 B (32 k) x 4 stages, or 128 B (64 k, a whole 128-byte line per row) x 2 stages —
-// both 80 KB; whole-line fetches fill LDS 1.3-1.4x faster (profiles/micro/lds_dma_rate.hip), so 128 is used when K % 64 == 0
+// ring geometry by bytes per LDS row: 64 B (32 k) x 2 stages (40 KB: the epilogue staging then sets the footprint, 53 KB,
+// three workgroups per CU), or 128 B (64 k, a whole 128-byte line per row) x 2 stages (80 KB, two per CU); whole-line
+// fetches fill LDS 1.3-1.4x faster (profiles/micro/lds_dma_rate.hip; the fill rate does not depend on the ring depth), so
+// 128 is used when K % 64 == 0 and K >= 512
 template <int BKB> struct GldsRing { static constexpr int stages = BKB == 64 ? GCV_GLDS_STAGES : 2; };
 
 template <typename T, int BKB = 64> struct GldsSmem {
