@@ -249,6 +249,119 @@ __global__ void __launch_bounds__(256) pack_dw_taps_kernel(const float* __restri
   out[i] = lo | (hi << 16);
 }
 
+// ------------------------------------------------------------------ K4 (16-bit, C = 384 / 768): packed-pair taps
+// Same decomposition as dwconv7_ln_kernel (one thread per channel of a 7x7 tile, inputs straight from global,
+// coalesced over channels), but the 49 fp32 taps become 28 pre-packed 16-bit pairs and the MACs v_dot2c: ~140 VGPRs
+// instead of 229, so the CU holds three waves per SIMD — two 6-wave workgroups at C = 384 instead of one.
+template <typename T, int C>
+__global__ void __launch_bounds__(C, 3)
+dwconv7_ln_pk_kernel(const T* __restrict__ x, const uint32_t* __restrict__ wpk /*[28][C]*/, const float* __restrict__ bdw,
+                     const float* __restrict__ lnw, const float* __restrict__ lnb, T* __restrict__ y, int nimg, int H,
+                     int W, float eps) {
+  static_assert(sizeof(T) == 2 && (C == 384 || C == 768), "packed-tap variant: 16-bit storage, C = 384 / 768");
+  extern __shared__ __attribute__((aligned(16))) float dwp_lds[];  // [49][C] values, then [49][2] stats
+  float* stats = dwp_lds + 49 * C;
+
+  const int tid = threadIdx.x;
+  const int c = tid;
+  const int tiles_x = (W + 6) / 7, tiles_y = (H + 6) / 7;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = tile % tiles_x, t2 = tile / tiles_x;
+  const int ty = t2 % tiles_y, b = t2 / tiles_y;
+  const int x0 = tx * 7, y0 = ty * 7;
+
+  uint32_t w2[28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) w2[k] = wpk[k * C + c];
+  const float bv = bdw[c];
+  float acc[49];
+#pragma unroll
+  for (int t = 0; t < 49; ++t) acc[t] = bv;
+
+  const unsigned short* xb = reinterpret_cast<const unsigned short*>(x) + (int64_t)b * H * W * C + c;
+  int xoff[13];
+  uint32_t xmask[13];
+#pragma unroll
+  for (int s = 0; s < 13; ++s) {
+    const int ix = x0 + s - 3;
+    xmask[s] = (ix >= 0 && ix < W) ? 0xffffu : 0u;
+    xoff[s] = min(max(ix, 0), W - 1) * C;
+  }
+  // halo rows in batches of RB: all 13*RB two-byte loads of a batch are independent and in flight together
+  constexpr int RB = 3;
+#pragma unroll
+  for (int rb = 0; rb < 13; rb += RB) {
+    uint32_t raw[RB][14];
+#pragma unroll
+    for (int rr = 0; rr < RB; ++rr) {
+      const int r = rb + rr;
+      if (r < 13) {
+        const int iy = y0 + r - 3;
+        const uint32_t rmask = (iy >= 0 && iy < H) ? 0xffffu : 0u;
+        const unsigned short* rp = xb + (int64_t)min(max(iy, 0), H - 1) * W * C;
+#pragma unroll
+        for (int s = 0; s < 13; ++s) raw[rr][s] = (uint32_t)rp[xoff[s]] & (rmask & xmask[s]);
+        raw[rr][13] = 0u;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int rr = 0; rr < RB; ++rr) {
+      const int r = rb + rr;
+      if (r < 13) {
+        uint32_t pp[13];
+#pragma unroll
+        for (int s = 0; s < 13; ++s) pp[s] = raw[rr][s] | (raw[rr][s + 1] << 16);
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+          const int oy = r - ky;
+          if (oy >= 0 && oy < 7) {
+#pragma unroll
+            for (int ox = 0; ox < 7; ++ox)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc[oy * 7 + ox] = Dot2<T>::run(pp[ox + 2 * j], w2[ky * 4 + j], acc[oy * 7 + ox]);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int p = 0; p < 49; ++p) dwp_lds[p * C + c] = acc[p];
+  __syncthreads();
+
+  const int grp = tid >> 5, gl = tid & 31;
+  constexpr int NG = C / 32;
+  for (int p = grp; p < 49; p += NG) {
+    const float* row = dwp_lds + p * C;
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < C / 32; ++k) s += row[gl + 32 * k];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * (1.0f / C);
+    float q = 0.0f;
+#pragma unroll
+    for (int k = 0; k < C / 32; ++k) { const float d = row[gl + 32 * k] - mean; q = fmaf(d, d, q); }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    if (gl == 0) {
+      stats[2 * p] = mean;
+      stats[2 * p + 1] = 1.0f / sqrtf(q * (1.0f / C) + eps);
+    }
+  }
+  __syncthreads();
+
+  const float lw = lnw[c], lb = lnb[c];
+  T* yb = y + (int64_t)b * H * W * C + c;
+#pragma unroll
+  for (int p = 0; p < 49; ++p) {
+    const int oy = y0 + p / 7, ox = x0 + p % 7;
+    if (oy < H && ox < W)
+      yb[((int64_t)oy * W + ox) * C] = from_f<T>((acc[p] - stats[2 * p]) * stats[2 * p + 1] * lw + lb);
+  }
+}
+
 #ifndef GCV_DW_ABLATE
 #define GCV_DW_ABLATE 0     // diagnostics: 1 one tap row, 2 no LN stats, 4 no tap packing, 8 no halo loads, 16 no stores
 #endif

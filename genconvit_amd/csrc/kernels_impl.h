@@ -57,6 +57,22 @@ static int launch_dw_v3(const T* x, const float* wdw, const float* bdw, const fl
   return 0;
 }
 
+template <typename T, int C>
+static int launch_dw_pk(const T* x, const uint32_t* wpk, const float* bdw, const float* lnw, const float* lnb, T* y, int nimg,
+                        int H, int W, float eps, hipStream_t s) {
+  constexpr size_t LDS = (size_t)49 * C * 4 + 49 * 2 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GCV_CHECK_HIP(hipFuncSetAttribute((const void*)dwconv7_ln_pk_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)LDS));
+    attr_set = true;
+  }
+  const int tiles = nimg * cdiv(H, 7) * cdiv(W, 7);
+  hipLaunchKernelGGL((dwconv7_ln_pk_kernel<T, C>), dim3(tiles), dim3(C), LDS, s, x, wpk, bdw, lnw, lnb, y, nimg, H, W, eps);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // GCV_DWCONV_MODE (A/B switch for profiling): 0 = v3 with packed-pair dot2 taps (default for 16-bit, C <= 192),
 // 1 = v3 with one output row per thread at C = 96, 2 = the generic kernel everywhere, 4 = v3 with fp32 FMA taps
 static inline int dwconv_mode() {
@@ -91,6 +107,12 @@ int launch_dwconv7_ln(const T* x, const float* wdw, const float* bdw, const floa
         if (mode == 0 || mode == 1) return launch_dw_v3<T, 192, 2, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
         if (mode == 4) return launch_dw_v3<T, 192, 2, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
       }
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (wpk && dwconv_mode() != 2) {                     // pre-packed taps available: packed-pair variant of the generic kernel
+      if (C == 384) return launch_dw_pk<T, 384>(x, wpk, bdw, lnw, lnb, y, nimg, H, W, eps, s);
+      if (C == 768) return launch_dw_pk<T, 768>(x, wpk, bdw, lnw, lnb, y, nimg, H, W, eps, s);
     }
   }
   switch (C) {

@@ -94,7 +94,7 @@ template <typename T> struct CnxBlockW {
   float *dw_w, *dw_b, *ln_w, *ln_b, *fc1_b, *fc2_b, *gamma;
   T *fc1_w, *fc2_w;
   T* fc2_wc;       // 16-bit, C <= 384: W2 packed for the fused MLP kernels (else null)
-  uint32_t* dw_wpk; // 16-bit, C <= 192: dw taps as packed pairs [28][C] for dwconv7_ln_v3_kernel (else null)
+  uint32_t* dw_wpk; // 16-bit: dw taps as packed pairs [28][C] for the dot2 dw7x7 kernels (fp32 storage: null)
 };
 template <typename T> struct CnxW {
   float *stem_w, *stem_b, *stem_lnw, *stem_lnb;
@@ -314,7 +314,7 @@ template <typename T> struct NetImpl : NetBase {
           GCV_UP(k.dw_w, st, t);
           k.dw_wpk = nullptr;
           if constexpr (sizeof(T) == 2) {
-            if (C <= 192) {
+            {
               k.dw_wpk = (uint32_t*)st.raw((size_t)28 * C * 4);
               if (!k.dw_wpk) { set_error("hipMalloc failed for packed dw taps"); return -5; }
               GCV_TRY(launch_pack_dw_taps<T>(k.dw_w, k.dw_wpk, C, nullptr));
