@@ -791,7 +791,7 @@ __global__ void __launch_bounds__(64) swin_window_attn_kernel(const T* __restric
 //                     image [d][key] whose key axis is pre-permuted to the accumulator's k order (8 MFMAs)
 // K and Q tiles live in LDS as [token][32] rows (64 B) read with ds_read_b128.
 template <typename T>
-__global__ void __launch_bounds__(64) swin_window_attn_mfma_kernel(const T* __restrict__ qkv,
+__global__ void __launch_bounds__(64, 3) swin_window_attn_mfma_kernel(const T* __restrict__ qkv,
                                                                   const float* __restrict__ rpb, T* __restrict__ out,
                                                                   int H, int W, int C, int nH, int shift,
                                                                   float scale) {
@@ -1059,7 +1059,7 @@ __global__ void __launch_bounds__(256) conv3_first_kernel(const T* __restrict__ 
   constexpr int PW = POOL ? 4 : 3;      // input patch width/height
   constexpr int NPOS = POOL ? 4 : 1;
   __shared__ __attribute__((aligned(16))) float sW[27 * 16];
-  __shared__ float sIn[PW * PW * 3][256];
+  __shared__ T sIn[PW * PW * 3][256];      // parked in the storage dtype: 24 KB instead of 48 KB for 16-bit -> twice the workgroups per CU
   const int tid = threadIdx.x;
   for (int i = tid; i < 27 * 16; i += 256) sW[i] = wp[i];
   const int Ho = H >> 1, Wo = W >> 1;
@@ -1080,7 +1080,7 @@ __global__ void __launch_bounds__(256) conv3_first_kernel(const T* __restrict__ 
       const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
 #pragma unroll
       for (int ci = 0; ci < 3; ++ci)
-        sIn[(r * PW + s) * 3 + ci][tid] = ok ? to_f(x[b * sb + ci * sc + (int64_t)iy * sy + (int64_t)ix * sx]) : 0.0f;
+        sIn[(r * PW + s) * 3 + ci][tid] = ok ? x[b * sb + ci * sc + (int64_t)iy * sy + (int64_t)ix * sx] : from_f<T>(0.0f);
     }
   __syncthreads();
   float acc[NPOS][16];
@@ -1101,7 +1101,7 @@ __global__ void __launch_bounds__(256) conv3_first_kernel(const T* __restrict__ 
     }
 #pragma unroll
     for (int q = 0; q < NPOS; ++q) {
-      const float v = sIn[(((q >> 1) + ky) * PW + (q & 1) + kx) * 3 + ci][tid];
+      const float v = to_f(sIn[(((q >> 1) + ky) * PW + (q & 1) + kx) * 3 + ci][tid]);
 #pragma unroll
       for (int co = 0; co < 16; ++co) acc[q][co] = fmaf(v, w[co], acc[q][co]);
     }
