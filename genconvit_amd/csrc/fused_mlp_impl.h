@@ -4,7 +4,7 @@
 
 #include "fused_mlp.h"
 #include "fused_mlp_res.h"
-#include "fused_mlp_c384.h"
+#include "fused_mlp_ring.h"
 
 namespace gcv {
 
@@ -25,8 +25,15 @@ __global__ void __launch_bounds__(256) pack_w2_chunks_kernel(const float* __rest
   out[i] = from_f<T>(w2[(int64_t)o * 4 * C + ch * HC + hid]);
 }
 
-// chunk width: 96 hidden for the C = 96 / 192 kernels, 32 (one MFMA k-group) for the C = 384 kernel
-static inline int mlp_chunk_width(int C) { return C == 384 ? 32 : kMlpHC; }
+// The LDS-DMA ring kernel (fused_mlp_ring.h) is the only fused kernel for C = 384; at C = 192 it is an experiment
+// (GCV_MLP_RING192=1: 288 us vs 279 us for the streaming kernel at 256 images — with two groups of prefetch the ring is
+// fill-latency bound: PMC shows 60 % of wave cycles in s_waitcnt / barrier).  The packed W2 layout follows the choice:
+// 32-wide hidden groups for the ring kernel, 96-wide chunks otherwise.
+static inline bool mlp_use_ring(int C) {
+  static const bool ring192 = [] { const char* e = std::getenv("GCV_MLP_RING192"); return e ? std::atoi(e) != 0 : false; }();
+  return C == 384 || (C == 192 && ring192);
+}
+static inline int mlp_chunk_width(int C) { return mlp_use_ring(C) ? 32 : kMlpHC; }
 
 template <typename T> int launch_pack_w2_chunks(const float* w2_dev, T* out, int C, hipStream_t s) {
   const int HC = mlp_chunk_width(C);
@@ -64,17 +71,25 @@ template <typename T> int launch_fused_mlp_res(const MlpArgs& a, hipStream_t s) 
   return 0;
 }
 
-template <typename T> int launch_fused_mlp_c384(const MlpArgs& a, hipStream_t s) {
-  constexpr int SMEM = Mlp384Smem::bytes;
+template <typename T, int C> static int launch_mlp_ring_c(const MlpArgs& a, hipStream_t s) {
+  constexpr int SMEM = MlpRingSmem<C>::bytes;
   static bool attr_done = false;
   if (!attr_done) {
-    GCV_CHECK_HIP(hipFuncSetAttribute((const void*)fused_mlp_c384_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
+    GCV_CHECK_HIP(hipFuncSetAttribute((const void*)fused_mlp_ring_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
     attr_done = true;
   }
   const int ntiles = cdiv(a.M, 128);
-  hipLaunchKernelGGL((fused_mlp_c384_kernel<T>), dim3(ntiles < 256 ? ntiles : 256), dim3(256), SMEM, s, a, ntiles);
+  const int slots = 256 * (C == 192 ? 2 : 1);              // persistent workgroups: two per CU at C = 192
+  hipLaunchKernelGGL((fused_mlp_ring_kernel<T, C>), dim3(ntiles < slots ? ntiles : slots), dim3(256), SMEM, s, a, ntiles);
   GCV_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+template <typename T> int launch_fused_mlp_ring(const MlpArgs& a, int C, hipStream_t s) {
+  if (C == 192) return launch_mlp_ring_c<T, 192>(a, s);
+  if (C == 384) return launch_mlp_ring_c<T, 384>(a, s);
+  set_error("ring MLP kernel: C = 192 / 384");
+  return -3;
 }
 
 template <typename T> int launch_fused_mlp(const MlpArgs& a, int C, hipStream_t s) {
@@ -85,8 +100,8 @@ template <typename T> int launch_fused_mlp(const MlpArgs& a, int C, hipStream_t 
   static const int res_mode = [] { const char* e = std::getenv("GCV_MLP_RESIDENT"); return e ? std::atoi(e) : 1; }();
   if (C == 96 && res_mode && a.M >= 256 * 8 * 32) return launch_fused_mlp_res<T>(a, s);
   if (C == 96) return launch_mlp_c<T, 96, 4>(a, s);
+  if (mlp_use_ring(C)) return launch_fused_mlp_ring<T>(a, C, s);
   if (C == 192) return launch_mlp_c<T, 192, 8>(a, s);
-  if (C == 384) return launch_fused_mlp_c384<T>(a, s);
   set_error("fused MLP is built for C = 96, 192 and 384");
   return -3;
 }

@@ -1,5 +1,10 @@
-// Fused ConvNeXt MLP for the C = 384 stage (16-bit storage):
-//     out = resid + gamma * ( W2 . GELU( W1 . x_ln + b1 ) + b2 ),   W1 (1536, 384), W2 (384, 1536)
+// Fused ConvNeXt MLP with LDS-DMA weight rings, C = 192 / 384 (16-bit storage):
+//     out = resid + gamma * ( W2 . GELU( W1 . x_ln + b1 ) + b2 ),   W1 (4C, C), W2 (C, 4C)
+//
+// Both instances are opt-in experiments (GCV_MLP_RING192=1, GCV_FUSED_MLP384=1), correct and unit-tested, slower than
+// what they would replace.  C = 192: 4-wave workgroups of 128 tokens, 78 KB of LDS -> two workgroups per CU, 96-register
+// output tile; 288 us vs 279 us for the streaming kernel (fill-latency bound: two groups of prefetch are ~one L2->LDS
+// latency).  C = 384 (text below): one workgroup per CU.
 //
 // Why: as two LDS-DMA GEMMs (pw1 + GELU, pw2 * gamma + res) this stage is bound by the L2 -> LDS fill rate of a CU —
 // every 128-token tile pulls its share of both weight matrices once per 192 output columns (31 KB of operands per
@@ -31,25 +36,34 @@
 
 namespace gcv {
 
-struct Mlp384Smem {
-  static constexpr int kW1Slot = 32 * 768;                  // one hidden group of W1: 32 rows x 384 k
-  static constexpr int kW2Slot = 384 * 64;                  // one hidden group of W2: 384 rows x 32 hidden
+template <int C> struct MlpRingSmem {
+  static constexpr int kW1Slot = 32 * C * 2;                // one hidden group of W1: 32 rows x C k
+  static constexpr int kW2Slot = C * 64;                    // one hidden group of W2: C rows x 32 hidden
   static constexpr int kSlots = 3;
   static constexpr int kW1 = 0;
-  static constexpr int kW2 = kSlots * kW1Slot;              // 73728
-  static constexpr int kB1 = kW2 + kSlots * kW2Slot;        // 147456: 1536 floats
-  static constexpr int kB2 = kB1 + 1536 * 4;                // 384 floats
-  static constexpr int kG = kB2 + 384 * 4;                  // 384 floats
-  static constexpr int bytes = kG + 384 * 4;                // 156672
+  static constexpr int kW2 = kSlots * kW1Slot;
+  static constexpr int kB1 = kW2 + kSlots * kW2Slot;        // 4C floats
+  static constexpr int kB2 = kB1 + 4 * C * 4;               // C floats
+  static constexpr int kG = kB2 + C * 4;                    // C floats
+  static constexpr int bytes = kG + C * 4;                  // 78336 (C = 192) / 156672 (C = 384)
 };
 
 #define GCV_M384_WAIT(N)  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory")
 
-template <typename T>
-__global__ void __launch_bounds__(256, 1) fused_mlp_c384_kernel(const MlpArgs a, const int ntiles) {
+template <typename T, int C>
+__global__ void __launch_bounds__(256, C == 192 ? 2 : 1) fused_mlp_ring_kernel(const MlpArgs a, const int ntiles) {
   static_assert(sizeof(T) == 2, "fused MLP is built for 16-bit storage");
-  constexpr int C = 384, NG = 48, KP1 = C / 16, NO = C / 32;          // 48 groups of 32 hidden, 24 k-steps, 12 out tiles
+  static_assert(C == 192 || C == 384, "ring kernel: C = 192 / 384");
+  typedef MlpRingSmem<C> Mlp384Smem;
+  constexpr int NG = 4 * C / 32, KP1 = C / 16, NO = C / 32;            // hidden groups of 32, GEMM1 k-steps, output tiles
+  constexpr int W1ROW = C * 2;                                         // bytes per W1 row
+  constexpr int NI = Mlp384Smem::kW1Slot / 4096;                       // DMA instructions per wave, ring part and stage (3 / 6)
   constexpr int W1S = Mlp384Smem::kW1Slot, W2S = Mlp384Smem::kW2Slot;
+  constexpr int FB = (C == 192) ? 3 : 6;                               // fragments read per batch (register budget: 256 / 512)
+  // swizzle of a W1 row's 16-byte chunk index: the 16 lanes of a ds_read_b128 group must hit 16 distinct units mod 16
+  auto swz1 = [](int row, int chunk) {
+    return C == 384 ? ((chunk & ~15) | ((chunk & 15) ^ (row & 15))) : ((chunk & ~7) | ((chunk & 7) ^ ((row >> 1) & 7)));
+  };
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const float* sB1 = reinterpret_cast<const float*>(smem + Mlp384Smem::kB1);
   const float* sB2 = reinterpret_cast<const float*>(smem + Mlp384Smem::kB2);
@@ -65,13 +79,13 @@ __global__ void __launch_bounds__(256, 1) fused_mlp_c384_kernel(const MlpArgs a,
   if (my_tiles <= 0) return;
 
   // ---- per-lane DMA source offsets (bytes inside one group's W1 rows / packed W2 block) ----
-  int off1[6], off2[6];
+  int off1[NI], off2[NI];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < NI; ++i) {
     const int q = wave + 4 * i;
     const int o = 1024 * q + 16 * lane;                                // byte offset in the lane-linear LDS image
-    const int row = o / 768, phys = (o - row * 768) >> 4;
-    off1[i] = row * 768 + (((phys & ~15) | ((phys & 15) ^ (row & 15))) << 4);
+    const int row = o / W1ROW, phys = (o - row * W1ROW) >> 4;
+    off1[i] = row * W1ROW + (swz1(row, phys) << 4);
     const int r2 = 16 * q + (lane >> 2), p2 = lane & 3;
     off2[i] = r2 * 64 + ((p2 ^ ((r2 >> 2) & 3)) << 4);
   }
@@ -81,7 +95,7 @@ __global__ void __launch_bounds__(256, 1) fused_mlp_c384_kernel(const MlpArgs a,
     const unsigned char* src = gW1 + (int64_t)(n % NG) * W1S;
     unsigned char* dst = smem + Mlp384Smem::kW1 + (n % 3) * W1S;
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < NI; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off1[i]),
                                        (__attribute__((address_space(3))) void*)(dst + (wave + 4 * i) * 1024), 16, 0, 0);
   };
@@ -89,7 +103,7 @@ __global__ void __launch_bounds__(256, 1) fused_mlp_c384_kernel(const MlpArgs a,
     const unsigned char* src = gW2 + (int64_t)(n % NG) * W2S;
     unsigned char* dst = smem + Mlp384Smem::kW2 + (n % 3) * W2S;
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < NI; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off2[i]),
                                        (__attribute__((address_space(3))) void*)(dst + (wave + 4 * i) * 1024), 16, 0, 0);
   };
@@ -97,11 +111,11 @@ __global__ void __launch_bounds__(256, 1) fused_mlp_c384_kernel(const MlpArgs a,
   // ---- biases / layer scale -> LDS; ring prologue: W1(0) | W1(1), W2(0) | W1(2), W2(1)  (12 DMAs per wave each) ----
   {
     float* sf = reinterpret_cast<float*>(smem + Mlp384Smem::kB1);
-    for (int i = tid; i < 1536 + 384 + 384; i += 256)
-      sf[i] = i < 1536 ? a.b1[i] : (i < 1920 ? a.b2[i - 1536] : a.gamma[i - 1920]);
+    for (int i = tid; i < 6 * C; i += 256)
+      sf[i] = i < 4 * C ? a.b1[i] : (i < 5 * C ? a.b2[i - 4 * C] : a.gamma[i - 5 * C]);
   }
   issue_w1(0);
-  issue_w1(0);                                                         // (twice: keeps every issue point at 12 DMAs per wave)
+  issue_w1(0);                                                         // (twice: keeps every issue point at 2*NI DMAs per wave)
   issue_w1(1); issue_w2(0);
   issue_w1(2); issue_w2(1);
   __syncthreads();                                                     // biases visible (this also drains the prologue DMAs)
@@ -109,7 +123,6 @@ __global__ void __launch_bounds__(256, 1) fused_mlp_c384_kernel(const MlpArgs a,
   const T* __restrict__ Xp = (const T*)a.X;
   const T* Rp = (const T*)a.resid;
   T* Op = (T*)a.out;
-  const int key4 = lr & 15;                                            // W1 swizzle key of this lane's row
   const int key2 = (lr >> 2) & 3;                                      // W2 swizzle key (32 o + lr: o adds 0 mod 4 to row >> 2)
 
   int n0 = 0;                                                          // global step of the current tile's group 0
@@ -135,67 +148,56 @@ __global__ void __launch_bounds__(256, 1) fused_mlp_c384_kernel(const MlpArgs a,
         for (int e = 0; e < 4; ++e) acc[4 * q + e] = bv[e];
       }
     };
-    // 6 k-steps of GEMM1 for the group in W1 slot `slot`: acc += W1[group][:, 16 p0 ..] . x
+    // FB k-steps of GEMM1 for the group in W1 slot `slot`: acc += W1[group][:, 16 p0 ..] . x
     auto gemm1_part = [&](int slot, int p0, f32x16& acc) {
-      const unsigned char* base = smem + Mlp384Smem::kW1 + slot * W1S + lr * 768;
-      u32x4 wf[6];
+      const unsigned char* base = smem + Mlp384Smem::kW1 + slot * W1S + lr * W1ROW;
+      u32x4 wf[FB];
 #pragma unroll
-      for (int p = 0; p < 6; ++p) {
-        const int k16 = 2 * (p0 + p) + lh;
-        wf[p] = *(const u32x4*)(base + (((k16 & ~15) | ((k16 & 15) ^ key4)) << 4));
-      }
+      for (int p = 0; p < FB; ++p) wf[p] = *(const u32x4*)(base + (swz1(lr, 2 * (p0 + p) + lh) << 4));
 #pragma unroll
-      for (int p = 0; p < 6; ++p) Mfma<T>::run(wf[p], xf[p0 + p], acc);
+      for (int p = 0; p < FB; ++p) Mfma<T>::run(wf[p], xf[p0 + p], acc);
     };
-    // GELU of 8 of the 16 hidden values a lane holds -> one 16-byte B fragment
+    // GELU of 8 of the 16 hidden values a lane holds -> one 16-byte B fragment (C = 192: four values at a time)
     auto gelu_half = [&](const f32x16& acc, int half, u32x4& hf) {
-      float hv[2][4];
-#pragma unroll
-      for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hv[qq][e] = acc[4 * (2 * half + qq) + e];
-      if (!(GCV_MLP_ABLATE & 1)) act4n<ACT_GELU, T, 2>(hv);
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq) {
-        const t4 h4 = {from_f<T>(hv[qq][0]), from_f<T>(hv[qq][1]), from_f<T>(hv[qq][2]), from_f<T>(hv[qq][3])};
+        float hv[1][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hv[0][e] = acc[4 * (2 * half + qq) + e];
+        act4n<ACT_GELU, T, 1>(hv);
+        const t4 h4 = {from_f<T>(hv[0][0]), from_f<T>(hv[0][1]), from_f<T>(hv[0][2]), from_f<T>(hv[0][3])};
         const uint2 pk = __builtin_bit_cast(uint2, h4);
         hf[2 * qq] = pk.x;
         hf[2 * qq + 1] = pk.y;
       }
     };
-    // GEMM2, k-step s (16 of the group's 32 hidden), output tiles o0 .. o0+5: acc2[o] += W2[32 o .., group][:, 16 s ..] . h_s
+    // GEMM2, k-step s (16 of the group's 32 hidden), output tiles o0 .. o0+FB-1: acc2[o] += W2[32 o .., group][:, 16 s ..] . h_s
     auto gemm2_part = [&](int slot, int s, int o0, const u32x4& hf) {
       const unsigned char* base = smem + Mlp384Smem::kW2 + slot * W2S + lr * 64 + (((2 * s + lh) ^ key2) << 4);
-      u32x4 w2f[6];
+      u32x4 w2f[FB];
 #pragma unroll
-      for (int o = 0; o < 6; ++o) w2f[o] = *(const u32x4*)(base + (o0 + o) * 32 * 64);
+      for (int o = 0; o < FB; ++o) w2f[o] = *(const u32x4*)(base + (o0 + o) * 32 * 64);
 #pragma unroll
-      for (int o = 0; o < 6; ++o) Mfma<T>::run(w2f[o], hf, acc2[o0 + o]);
+      for (int o = 0; o < FB; ++o) Mfma<T>::run(w2f[o], hf, acc2[o0 + o]);
     };
     // one step: C holds b1 + W1[g] . x ; computes N for g+1 (unless last), h(g), acc2 += W2[:, g] . h(g)
     auto step = [&](int g, f32x16& Cacc, f32x16& Nacc) {
       const int n = n0 + g;
-      GCV_M384_WAIT(12);                                               // W1(n+1), W2(n) landed everywhere; step n-1 is over
+      GCV_M384_WAIT(2 * NI);                                           // W1(n+1), W2(n) landed everywhere; step n-1 is over
       issue_w1(n + 3);                                                 // (past the last tile these fetch groups nobody reads:
-      issue_w2(n + 2);                                                 //  the count stays at 12 DMAs per wave and step)
+      issue_w2(n + 2);                                                 //  the count stays at 2*NI DMAs per wave and step)
       u32x4 hf[2];
       if (g + 1 < NG) {
         load_b1(g + 1, Nacc);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-          gemm1_part((n + 1) % 3, 12 * half, Nacc);
-          gemm1_part((n + 1) % 3, 12 * half + 6, Nacc);
-          gelu_half(Cacc, half, hf[half]);
 #pragma unroll
-          for (int part = 0; part < ((GCV_MLP_ABLATE & 16) ? 0 : 2); ++part) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);         // 6 fragment reads
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-              __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);       // 9 VALU
-              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // 1 MFMA
-            }
+          for (int part = 0; part < KP1 / 2 / FB; ++part) {
+            gemm1_part((n + 1) % 3, (KP1 / 2) * half + FB * part, Nacc);
+            __builtin_amdgcn_sched_barrier(0);
           }
+          gelu_half(Cacc, half, hf[half]);
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
@@ -206,7 +208,7 @@ __global__ void __launch_bounds__(256, 1) fused_mlp_c384_kernel(const MlpArgs a,
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int o0 = 0; o0 < NO; o0 += 6) {
+        for (int o0 = 0; o0 < NO; o0 += FB) {
           gemm2_part(n % 3, s, o0, hf[s]);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -216,7 +218,7 @@ __global__ void __launch_bounds__(256, 1) fused_mlp_c384_kernel(const MlpArgs a,
     f32x16 accA, accB;
     load_b1(0, accA);
 #pragma unroll
-    for (int p0 = 0; p0 < KP1; p0 += 6) {
+    for (int p0 = 0; p0 < KP1; p0 += FB) {
       gemm1_part(n0 % 3, p0, accA);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -256,6 +258,6 @@ __global__ void __launch_bounds__(256, 1) fused_mlp_c384_kernel(const MlpArgs a,
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // no DMA may outlive the workgroup's LDS
 }
 
-template <typename T> int launch_fused_mlp_c384(const MlpArgs& a, hipStream_t s);
+template <typename T> int launch_fused_mlp_ring(const MlpArgs& a, int C, hipStream_t s);
 
 }  // namespace gcv

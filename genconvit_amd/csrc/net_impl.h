@@ -152,7 +152,7 @@ template <typename T> struct NetImpl : NetBase {
   Arena arena;
   hipStream_t cur = nullptr;
   bool use_fused_mlp = std::getenv("GCV_NO_FUSED_MLP") == nullptr;   // A/B switches for profiling
-  // the C = 384 fused kernel (fused_mlp_c384.h) is correct but measures 309 us against 216 us for pw1 + pw2 at 256
+  // the C = 384 ring kernel (fused_mlp_ring.h) is correct but measures 309 us against 216 us for pw1 + pw2 at 256
   // images (one wave per SIMD cannot hide its LDS / MFMA latencies): opt-in for experiments only
   bool use_fused_mlp384 = std::getenv("GCV_FUSED_MLP384") != nullptr;
 
