@@ -50,16 +50,53 @@ template <> struct Vec16<float>  { float v[4]; };
 template <> struct Vec16<half_t> { half_t v[8]; };
 template <> struct Vec16<bf16_t> { bf16_t v[8]; };
 
-// wave-level reductions (64 lanes)
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- cross-lane reductions --------------------------------------------------------------------------
+// Inside a 16-lane DPP row the exchange is a modifier of the v_add / v_max itself (no LDS traffic); __shfl_xor
+// always compiles to ds_bpermute_b32, an LDS-pipe instruction with its own address register — the LayerNorm
+// statistics loops issued almost as many of those as the depthwise taps issued real LDS reads.
+#define GCV_DPP_F32(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
+// xor-1 / xor-2 inside quads (quad_perm [1,0,3,2] / [2,3,0,1]), then row_half_mirror and row_mirror: every lane of the
+// row ends up with the reduction over the row's 16 lanes
+__device__ __forceinline__ float row16_sum(float v) {
+  v += GCV_DPP_F32(v, 0xB1);
+  v += GCV_DPP_F32(v, 0x4E);
+  v += GCV_DPP_F32(v, 0x141);
+  v += GCV_DPP_F32(v, 0x140);
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, GCV_DPP_F32(v, 0xB1));
+  v = fmaxf(v, GCV_DPP_F32(v, 0x4E));
+  v = fmaxf(v, GCV_DPP_F32(v, 0x141));
+  v = fmaxf(v, GCV_DPP_F32(v, 0x140));
   return v;
+}
+// aligned groups of 4 / 8 lanes (quads, half rows)
+__device__ __forceinline__ float group8_sum(float v) {
+  v += GCV_DPP_F32(v, 0xB1);
+  v += GCV_DPP_F32(v, 0x4E);
+  v += GCV_DPP_F32(v, 0x141);
+  return v;
+}
+// aligned groups of 32 lanes: two rows, one cross-row exchange through the LDS crossbar
+__device__ __forceinline__ float group32_sum(float v) {
+  v = row16_sum(v);
+  return v + __shfl_xor(v, 16, 64);
+}
+// whole wave (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+  v = group32_sum(v);
+  return v + __shfl_xor(v, 32, 64);
+}
+// aligned groups of N lanes, N = 16 / 32 / 64
+template <int N> __device__ __forceinline__ float group_sum(float v) {
+  static_assert(N == 16 || N == 32 || N == 64, "group_sum: 16 / 32 / 64 lanes");
+  return N == 16 ? row16_sum(v) : (N == 32 ? group32_sum(v) : wave_sum(v));
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = row16_max(v);
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
 }
 
 // ---- host side -------------------------------------------------------------

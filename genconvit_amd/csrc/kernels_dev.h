@@ -61,12 +61,12 @@ __global__ void __launch_bounds__(256) stem_ln_kernel(const T* __restrict__ x, i
   float s = 0.0f;
 #pragma unroll
   for (int i = 0; i < 12; ++i) s += acc[i];
-  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+  s = group8_sum(s);
   const float mean = s * (1.0f / 96.0f);
   float q = 0.0f;
 #pragma unroll
   for (int i = 0; i < 12; ++i) { const float d = acc[i] - mean; q = fmaf(d, d, q); }
-  q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+  q = group8_sum(q);
   const float rstd = 1.0f / sqrtf(q * (1.0f / 96.0f) + eps);
   const int64_t gp = p0 + p;
   if (gp < total) {
@@ -182,14 +182,12 @@ dwconv7_ln_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*[49][
     float s = 0.0f;
 #pragma unroll
     for (int k = 0; k < C / 32; ++k) s += row[gl + 32 * k];
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    s = group32_sum(s);
     const float mean = s * (1.0f / C);
     float q = 0.0f;
 #pragma unroll
     for (int k = 0; k < C / 32; ++k) { const float d = row[gl + 32 * k] - mean; q = fmaf(d, d, q); }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    q = group32_sum(q);
     if (gl == 0) {
       stats[2 * p] = mean;
       stats[2 * p + 1] = 1.0f / sqrtf(q * (1.0f / C) + eps);
@@ -337,14 +335,12 @@ dwconv7_ln_pk_kernel(const T* __restrict__ x, const uint32_t* __restrict__ wpk /
     float s = 0.0f;
 #pragma unroll
     for (int k = 0; k < C / 32; ++k) s += row[gl + 32 * k];
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    s = group32_sum(s);
     const float mean = s * (1.0f / C);
     float q = 0.0f;
 #pragma unroll
     for (int k = 0; k < C / 32; ++k) { const float d = row[gl + 32 * k] - mean; q = fmaf(d, d, q); }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    q = group32_sum(q);
     if (gl == 0) {
       stats[2 * p] = mean;
       stats[2 * p + 1] = 1.0f / sqrtf(q * (1.0f / C) + eps);
@@ -532,14 +528,12 @@ dwconv7_ln_v3_kernel(const T* __restrict__ x, const float* __restrict__ wdw, con
       float s = 0.0f;
 #pragma unroll
       for (int k = 0; k < C / 32; ++k) s += row[gl + 32 * k];
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      s = group32_sum(s);
       const float mean = s * (1.0f / C);
       float q = 0.0f;
 #pragma unroll
       for (int k = 0; k < C / 32; ++k) { const float d = row[gl + 32 * k] - mean; q = fmaf(d, d, q); }
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+      q = group32_sum(q);
       if (gl == 0) {
         stats[2 * p] = mean;
         stats[2 * p + 1] = 1.0f / sqrtf(q * (1.0f / C) + eps);
@@ -645,14 +639,12 @@ __global__ void __launch_bounds__(256) ln_patchify_vec_kernel(const T* __restric
     v[2 * k + 1] = from_bits16<T>(u >> 16);
     s += v[2 * k] + v[2 * k + 1];
   }
-#pragma unroll
-  for (int o = LPP / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  s = group_sum<LPP>(s);
   const float mean = s * (1.0f / C);
   float q = 0.0f;
 #pragma unroll
   for (int k = 0; k < 6; ++k) { const float d = v[k] - mean; q = fmaf(d, d, q); }
-#pragma unroll
-  for (int o = LPP / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  q = group_sum<LPP>(q);
   const float rstd = 1.0f / sqrtf(q * (1.0f / C) + eps);
   if (!live || iy >= 2 * Ho || ix >= 2 * Wo) return;
   uint32_t* dst = reinterpret_cast<uint32_t*>(out + ((b * Ho + (iy >> 1)) * Wo + (ix >> 1)) * 4 * C +
