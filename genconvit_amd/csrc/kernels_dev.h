@@ -179,14 +179,15 @@ dwconv7_ln_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*[49][
   constexpr int NG = TPB / 32;
   for (int p = grp; p < NP; p += NG) {
     const float* row = dw_lds + p * C;
+    float rv[C / 32];                                // the pixel's values stay in registers for both passes
     float s = 0.0f;
 #pragma unroll
-    for (int k = 0; k < C / 32; ++k) s += row[gl + 32 * k];
+    for (int k = 0; k < C / 32; ++k) { rv[k] = row[gl + 32 * k]; s += rv[k]; }
     s = group32_sum(s);
     const float mean = s * (1.0f / C);
     float q = 0.0f;
 #pragma unroll
-    for (int k = 0; k < C / 32; ++k) { const float d = row[gl + 32 * k] - mean; q = fmaf(d, d, q); }
+    for (int k = 0; k < C / 32; ++k) { const float d = rv[k] - mean; q = fmaf(d, d, q); }
     q = group32_sum(q);
     if (gl == 0) {
       stats[2 * p] = mean;
@@ -332,14 +333,15 @@ dwconv7_ln_pk_kernel(const T* __restrict__ x, const uint32_t* __restrict__ wpk /
   constexpr int NG = C / 32;
   for (int p = grp; p < 49; p += NG) {
     const float* row = dwp_lds + p * C;
+    float rv[C / 32];                                // the pixel's values stay in registers for both passes
     float s = 0.0f;
 #pragma unroll
-    for (int k = 0; k < C / 32; ++k) s += row[gl + 32 * k];
+    for (int k = 0; k < C / 32; ++k) { rv[k] = row[gl + 32 * k]; s += rv[k]; }
     s = group32_sum(s);
     const float mean = s * (1.0f / C);
     float q = 0.0f;
 #pragma unroll
-    for (int k = 0; k < C / 32; ++k) { const float d = row[gl + 32 * k] - mean; q = fmaf(d, d, q); }
+    for (int k = 0; k < C / 32; ++k) { const float d = rv[k] - mean; q = fmaf(d, d, q); }
     q = group32_sum(q);
     if (gl == 0) {
       stats[2 * p] = mean;
@@ -525,14 +527,15 @@ dwconv7_ln_v3_kernel(const T* __restrict__ x, const float* __restrict__ wdw, con
     const int grp = tid >> 5, gl = tid & 31;
     for (int p = grp; p < ((GCV_DW_ABLATE & 2) ? 0 : 49); p += NT / 32) {
       const float* row = sval + p * C;
+      float rv[C / 32];                                // the pixel's values stay in registers for both passes
       float s = 0.0f;
 #pragma unroll
-      for (int k = 0; k < C / 32; ++k) s += row[gl + 32 * k];
+      for (int k = 0; k < C / 32; ++k) { rv[k] = row[gl + 32 * k]; s += rv[k]; }
       s = group32_sum(s);
       const float mean = s * (1.0f / C);
       float q = 0.0f;
 #pragma unroll
-      for (int k = 0; k < C / 32; ++k) { const float d = row[gl + 32 * k] - mean; q = fmaf(d, d, q); }
+      for (int k = 0; k < C / 32; ++k) { const float d = rv[k] - mean; q = fmaf(d, d, q); }
       q = group32_sum(q);
       if (gl == 0) {
         stats[2 * p] = mean;
