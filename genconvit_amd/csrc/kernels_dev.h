@@ -16,6 +16,15 @@
 
 namespace gcv {
 
+// 16-bit storage values as raw bits (packed-pair math, LDS images)
+template <typename T> __device__ __forceinline__ uint32_t bits16(float v) {
+  const T t = from_f<T>(v);
+  return (uint32_t)__builtin_bit_cast(unsigned short, t);
+}
+template <typename T> __device__ __forceinline__ float from_bits16(uint32_t u) {
+  return to_f(__builtin_bit_cast(T, (unsigned short)u));
+}
+
 // ------------------------------------------------------------------ K3: stem
 // conv 4x4 stride 4 (3 -> 96) + LayerNorm over the 96 channels, output NHWC tokens.
 // Input addressed by element strides so NCHW frames and the NHWC reconstruction both work.
@@ -32,19 +41,58 @@ __global__ void __launch_bounds__(256) stem_ln_kernel(const T* __restrict__ x, i
   for (int i = tid; i < 48 * 96; i += 256) sW[i] = wp[i];
   const int64_t total = (int64_t)nimg * Ho * Wo;
   const int64_t p0 = (int64_t)blockIdx.x * 32;
-  for (int e = tid; e < 32 * 48; e += 256) {
-    const int p = e / 48, k = e - p * 48;
-    const int64_t gp = p0 + p;
-    float v = 0.0f;
-    if (gp < total) {
-      const int xo = (int)(gp % Wo);
-      const int64_t t = gp / Wo;
-      const int yo = (int)(t % Ho);
-      const int64_t b = t / Ho;
-      const int ci = k >> 4, ky = (k >> 2) & 3, kx = k & 3;
-      v = to_f(x[b * sb + ci * sc + (int64_t)(4 * yo + ky) * sy + (int64_t)(4 * xo + kx) * sx]);
+  // patch staging.  Both layouts the path uses keep 4 consecutive patch elements contiguous in memory — NCHW: the 4 kx
+  // of one (ci, ky); NHWC: 4 of the 12 (kx, ci) of one ky — so a work item is one 8-byte load (per-element staging
+  // spent ~20 integer instructions and one 2-byte load on each of the 48 patch elements).
+  const bool al = (reinterpret_cast<uintptr_t>(x) & 7u) == 0 && ((sb | sy) & 3) == 0;
+  const bool nchw4 = sizeof(T) == 2 && al && sx == 1 && (sc & 3) == 0;
+  const bool nhwc4 = sizeof(T) == 2 && al && sc == 1 && sx == 3;
+  if constexpr (sizeof(T) == 2) {
+   if (nchw4 || nhwc4) {
+    for (int e = tid; e < 32 * 12; e += 256) {
+      const int p = e / 12, r = e - p * 12;              // NCHW: r = ci*4 + ky ; NHWC: r = ky*3 + third
+      const int64_t gp = p0 + p;
+      uint2 raw = {0u, 0u};
+      const int ky = nchw4 ? (r & 3) : (r / 3);
+      const int sub = nchw4 ? (r >> 2) : (r - 3 * ky);   // NCHW: ci ; NHWC: which third of the 12 (kx, ci) elements
+      if (gp < total) {
+        const int xo = (int)(gp % Wo);
+        const int64_t t = gp / Wo;
+        const int yo = (int)(t % Ho);
+        const int64_t b = t / Ho;
+        const int64_t base = b * sb + (int64_t)(4 * yo + ky) * sy +
+                             (nchw4 ? (int64_t)sub * sc + 4 * xo : (int64_t)12 * xo + 4 * sub);
+        raw = *reinterpret_cast<const uint2*>(x + base);
+      }
+      const uint32_t h[4] = {raw.x & 0xffffu, raw.x >> 16, raw.y & 0xffffu, raw.y >> 16};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = from_bits16<T>(h[j]);
+        if (nchw4) {
+          sIn[p][sub * 16 + ky * 4 + j] = v;             // k = ci*16 + ky*4 + kx
+        } else {
+          const int el = 4 * sub + j, kx = el / 3, ci = el - 3 * kx;
+          sIn[p][ci * 16 + ky * 4 + kx] = v;
+        }
+      }
     }
-    sIn[p][k] = v;
+   }
+  }
+  if (!(nchw4 || nhwc4)) {
+    for (int e = tid; e < 32 * 48; e += 256) {
+      const int p = e / 48, k = e - p * 48;
+      const int64_t gp = p0 + p;
+      float v = 0.0f;
+      if (gp < total) {
+        const int xo = (int)(gp % Wo);
+        const int64_t t = gp / Wo;
+        const int yo = (int)(t % Ho);
+        const int64_t b = t / Ho;
+        const int ci = k >> 4, ky = (k >> 2) & 3, kx = k & 3;
+        v = to_f(x[b * sb + ci * sc + (int64_t)(4 * yo + ky) * sy + (int64_t)(4 * xo + kx) * sx]);
+      }
+      sIn[p][k] = v;
+    }
   }
   __syncthreads();
   const int p = tid >> 3, cg = tid & 7;
@@ -227,13 +275,6 @@ template <> struct Dot2<bf16_t> {
   }
 };
 
-template <typename T> __device__ __forceinline__ uint32_t bits16(float v) {
-  const T t = from_f<T>(v);
-  return (uint32_t)__builtin_bit_cast(unsigned short, t);
-}
-template <typename T> __device__ __forceinline__ float from_bits16(uint32_t u) {
-  return to_f(__builtin_bit_cast(T, (unsigned short)u));
-}
 
 // taps (49, C) fp32 -> [28][C] dwords of packed 16-bit pairs (tap(ky,2j), tap(ky,2j+1)), tap(ky,7) = 0: the LDS image
 // the v3 kernel works from.  Built once when the weights are loaded (per tile it cost 11 % of the C=96 kernel).
