@@ -29,18 +29,19 @@ template <typename T> __device__ __forceinline__ float from_bits16(uint32_t u) {
 // conv 4x4 stride 4 (3 -> 96) + LayerNorm over the 96 channels, output NHWC tokens.
 // Input addressed by element strides so NCHW frames and the NHWC reconstruction both work.
 // wp: [48][96] fp32 with k = ci*16 + ky*4 + kx.
+constexpr int kStemTok = 128;          // tokens per workgroup
 template <typename T>
 __global__ void __launch_bounds__(256) stem_ln_kernel(const T* __restrict__ x, int64_t sb, int64_t sc, int64_t sy,
                                                       int64_t sx, const float* __restrict__ wp,
                                                       const float* __restrict__ bias, const float* __restrict__ lnw,
                                                       const float* __restrict__ lnb, T* __restrict__ out, int nimg,
                                                       int Ho, int Wo, float eps) {
-  __shared__ float sW[48 * 96];
-  __shared__ float sIn[32][49];
+  __shared__ __attribute__((aligned(16))) float sW[48 * 96];
+  __shared__ float sIn[kStemTok][49];
   const int tid = threadIdx.x;
-  for (int i = tid; i < 48 * 96; i += 256) sW[i] = wp[i];
+  for (int i = tid; i < 48 * 96 / 4; i += 256) reinterpret_cast<float4*>(sW)[i] = reinterpret_cast<const float4*>(wp)[i];
   const int64_t total = (int64_t)nimg * Ho * Wo;
-  const int64_t p0 = (int64_t)blockIdx.x * 32;
+  const int64_t p0 = (int64_t)blockIdx.x * kStemTok;
   // patch staging.  Both layouts the path uses keep 4 consecutive patch elements contiguous in memory — NCHW: the 4 kx
   // of one (ci, ky); NHWC: 4 of the 12 (kx, ci) of one ky — so a work item is one 8-byte load (per-element staging
   // spent ~20 integer instructions and one 2-byte load on each of the 48 patch elements).
@@ -49,7 +50,7 @@ __global__ void __launch_bounds__(256) stem_ln_kernel(const T* __restrict__ x, i
   const bool nhwc4 = sizeof(T) == 2 && al && sc == 1 && sx == 3;
   if constexpr (sizeof(T) == 2) {
    if (nchw4 || nhwc4) {
-    for (int e = tid; e < 32 * 12; e += 256) {
+    for (int e = tid; e < kStemTok * 12; e += 256) {
       const int p = e / 12, r = e - p * 12;              // NCHW: r = ci*4 + ky ; NHWC: r = ky*3 + third
       const int64_t gp = p0 + p;
       uint2 raw = {0u, 0u};
@@ -79,7 +80,7 @@ __global__ void __launch_bounds__(256) stem_ln_kernel(const T* __restrict__ x, i
    }
   }
   if (!(nchw4 || nhwc4)) {
-    for (int e = tid; e < 32 * 48; e += 256) {
+    for (int e = tid; e < kStemTok * 48; e += 256) {
       const int p = e / 48, k = e - p * 48;
       const int64_t gp = p0 + p;
       float v = 0.0f;
@@ -95,34 +96,50 @@ __global__ void __launch_bounds__(256) stem_ln_kernel(const T* __restrict__ x, i
     }
   }
   __syncthreads();
-  const int p = tid >> 3, cg = tid & 7;
-  float acc[12];
+  // thread = (4 tokens, 12-channel group): three float4 of weights from LDS feed 48 FMAs (one token per thread issued
+  // 13 LDS reads per 12 FMAs)
+  const int pq = tid >> 3, cg = tid & 7;               // tokens 4 pq .. 4 pq + 3, channels 12 cg .. 12 cg + 11
+  float acc[4][12];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) acc[i] = bias[cg * 12 + i];
-#pragma unroll 4
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[t][i] = bias[cg * 12 + i];
+#pragma unroll 2
   for (int k = 0; k < 48; ++k) {
-    const float xv = sIn[p][k];
-    const float* wr = sW + k * 96 + cg * 12;
+    const float4* wr = reinterpret_cast<const float4*>(sW + k * 96 + cg * 12);
+    float w[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) acc[i] = fmaf(xv, wr[i], acc[i]);
+    for (int g4 = 0; g4 < 3; ++g4) {
+      const float4 v4 = wr[g4];
+      w[4 * g4] = v4.x; w[4 * g4 + 1] = v4.y; w[4 * g4 + 2] = v4.z; w[4 * g4 + 3] = v4.w;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const float xv = sIn[4 * pq + t][k];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) acc[t][i] = fmaf(xv, w[i], acc[t][i]);
+    }
   }
-  float s = 0.0f;
+  float lw[12], lb[12];
 #pragma unroll
-  for (int i = 0; i < 12; ++i) s += acc[i];
-  s = group8_sum(s);
-  const float mean = s * (1.0f / 96.0f);
-  float q = 0.0f;
+  for (int i = 0; i < 12; ++i) { lw[i] = lnw[cg * 12 + i]; lb[i] = lnb[cg * 12 + i]; }
 #pragma unroll
-  for (int i = 0; i < 12; ++i) { const float d = acc[i] - mean; q = fmaf(d, d, q); }
-  q = group8_sum(q);
-  const float rstd = 1.0f / sqrtf(q * (1.0f / 96.0f) + eps);
-  const int64_t gp = p0 + p;
-  if (gp < total) {
-    T* o = out + gp * 96 + cg * 12;
+  for (int t = 0; t < 4; ++t) {
+    float s = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      const int c = cg * 12 + i;
-      o[i] = from_f<T>((acc[i] - mean) * rstd * lnw[c] + lnb[c]);
+    for (int i = 0; i < 12; ++i) s += acc[t][i];
+    s = group8_sum(s);
+    const float mean = s * (1.0f / 96.0f);
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { const float d = acc[t][i] - mean; q = fmaf(d, d, q); }
+    q = group8_sum(q);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / 96.0f) + eps);
+    const int64_t gp = p0 + 4 * pq + t;
+    if (gp < total) {
+      T* o = out + gp * 96 + cg * 12;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) o[i] = from_f<T>((acc[t][i] - mean) * rstd * lw[i] + lb[i]);
     }
   }
 }

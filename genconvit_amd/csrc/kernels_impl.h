@@ -12,7 +12,8 @@ int launch_stem_ln(const T* x, int64_t sb, int64_t sc, int64_t sy, int64_t sx, c
                    const float* lnw, const float* lnb, T* out, int nimg, int Ho, int Wo, float eps, hipStream_t s) {
   const int64_t total = (int64_t)nimg * Ho * Wo;
   GCV_REQUIRE(total > 0, "stem: empty");
-  hipLaunchKernelGGL((stem_ln_kernel<T>), dim3((unsigned)cdiv64(total, 32)), dim3(256), 0, s, x, sb, sc, sy, sx, wp,
+  GCV_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15u) == 0, "stem: packed weights must be 16-byte aligned");
+  hipLaunchKernelGGL((stem_ln_kernel<T>), dim3((unsigned)cdiv64(total, kStemTok)), dim3(256), 0, s, x, sb, sc, sy, sx, wp,
                      bias, lnw, lnb, out, nimg, Ho, Wo, eps);
   GCV_CHECK_HIP(hipGetLastError());
   return 0;
