@@ -344,11 +344,12 @@ dwconv7_ln_pk_kernel(const T* __restrict__ x, const uint32_t* __restrict__ wpk /
     xmask[s] = (ix >= 0 && ix < W) ? 0xffffu : 0u;
     xoff[s] = min(max(ix, 0), W - 1) * C;
   }
-  // halo rows in batches of RB: all 13*RB two-byte loads of a batch are independent and in flight together
-  constexpr int RB = 3;
-#pragma unroll
-  for (int rb = 0; rb < 13; rb += RB) {
-    uint32_t raw[RB][14];
+  // halo rows in batches of RB, software-pipelined: the 13*RB two-byte loads of batch i+1 are issued before the taps
+  // of batch i run, so a thread waits for global memory once, not once per batch
+  constexpr int RB = 2;
+  constexpr int NBATCH = (13 + RB - 1) / RB;
+  uint32_t raw[2][RB][14];
+  auto load_batch = [&](int rb, uint32_t (&dst)[RB][14]) {
 #pragma unroll
     for (int rr = 0; rr < RB; ++rr) {
       const int r = rb + rr;
@@ -357,10 +358,16 @@ dwconv7_ln_pk_kernel(const T* __restrict__ x, const uint32_t* __restrict__ wpk /
         const uint32_t rmask = (iy >= 0 && iy < H) ? 0xffffu : 0u;
         const unsigned short* rp = xb + (int64_t)min(max(iy, 0), H - 1) * W * C;
 #pragma unroll
-        for (int s = 0; s < 13; ++s) raw[rr][s] = (uint32_t)rp[xoff[s]] & (rmask & xmask[s]);
-        raw[rr][13] = 0u;
+        for (int s = 0; s < 13; ++s) dst[rr][s] = (uint32_t)rp[xoff[s]] & (rmask & xmask[s]);
+        dst[rr][13] = 0u;
       }
     }
+  };
+  load_batch(0, raw[0]);
+#pragma unroll
+  for (int bi = 0; bi < NBATCH; ++bi) {
+    const int rb = bi * RB;
+    if (bi + 1 < NBATCH) load_batch(rb + RB, raw[(bi + 1) & 1]);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int rr = 0; rr < RB; ++rr) {
@@ -368,7 +375,7 @@ dwconv7_ln_pk_kernel(const T* __restrict__ x, const uint32_t* __restrict__ wpk /
       if (r < 13) {
         uint32_t pp[13];
 #pragma unroll
-        for (int s = 0; s < 13; ++s) pp[s] = raw[rr][s] | (raw[rr][s + 1] << 16);
+        for (int s = 0; s < 13; ++s) pp[s] = raw[bi & 1][rr][s] | (raw[bi & 1][rr][s + 1] << 16);
 #pragma unroll
         for (int ky = 0; ky < 7; ++ky) {
           const int oy = r - ky;
