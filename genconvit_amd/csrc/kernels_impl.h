@@ -74,7 +74,8 @@ static int launch_dw_pk(const T* x, const uint32_t* wpk, const float* bdw, const
   return 0;
 }
 
-// GCV_DWCONV_MODE (A/B switch for profiling): 0 = v3 with packed-pair dot2 taps (default for 16-bit, C <= 192),
+// GCV_DWCONV_MODE (A/B switch for profiling): 0 = rolling-strip kernel (default); 8 = the round-1 tile kernels: v3 with
+// packed-pair dot2 taps (16-bit, C <= 192) / packed-tap generic (C >= 384),
 // 1 = v3 with one output row per thread at C = 96, 2 = the generic kernel everywhere, 4 = v3 with fp32 FMA taps
 static inline int dwconv_mode() {
   static const int mode = [] { const char* e = std::getenv("GCV_DWCONV_MODE"); return e ? std::atoi(e) : 0; }();
@@ -95,8 +96,12 @@ template <typename T>
 int launch_dwconv7_ln(const T* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb, T* y,
                       int nimg, int H, int W, int C, float eps, hipStream_t s, const uint32_t* wpk) {
   GCV_REQUIRE(nimg > 0 && H > 0 && W > 0, "dwconv: empty");
+  // default: the rolling-strip kernel (every ConvNeXt-T shape but the 3x3 map of the 112-px pass)
+  if (dwconv_mode() == 0 && dwconv_roll_applicable<T>(H, W, C) &&
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) == 0)
+    return launch_dwconv7_ln_roll<T>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, C, eps, s);
   if constexpr (sizeof(T) == 2) {
-    const int mode = dwconv_mode();
+    const int mode = dwconv_mode() == 8 ? 0 : dwconv_mode();
     if (mode != 2 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0) {
       if (C == 96) {
         // two output rows per thread: 384 threads, three workgroups per CU
@@ -111,7 +116,7 @@ int launch_dwconv7_ln(const T* x, const float* wdw, const float* bdw, const floa
     }
   }
   if constexpr (sizeof(T) == 2) {
-    if (wpk && dwconv_mode() != 2) {                     // pre-packed taps available: packed-pair variant of the generic kernel
+    if (wpk && dwconv_mode() != 2) {                    // pre-packed taps available: packed-pair variant of the generic kernel
       if (C == 384) return launch_dw_pk<T, 384>(x, wpk, bdw, lnw, lnb, y, nimg, H, W, eps, s);
       if (C == 768) return launch_dw_pk<T, 768>(x, wpk, bdw, lnw, lnb, y, nimg, H, W, eps, s);
     }
