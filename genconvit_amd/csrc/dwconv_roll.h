@@ -42,6 +42,8 @@ template <> struct DwElem<float> {
 };
 template <> struct DwElem<half_t> {
   static constexpr int EPC = 8;
+  __device__ static __forceinline__ float lo(uint32_t v) { return (float)__builtin_bit_cast(_Float16, (uint16_t)v); }
+  __device__ static __forceinline__ float hi(uint32_t v) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(v >> 16)); }
   __device__ static __forceinline__ uint32_t pack2(float a, float b) {
     return (uint32_t)__builtin_bit_cast(uint16_t, (half_t)a) | ((uint32_t)__builtin_bit_cast(uint16_t, (half_t)b) << 16);
   }
@@ -57,6 +59,8 @@ template <> struct DwElem<half_t> {
 };
 template <> struct DwElem<bf16_t> {
   static constexpr int EPC = 8;
+  __device__ static __forceinline__ float lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
+  __device__ static __forceinline__ float hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
   __device__ static __forceinline__ uint32_t pack2(float a, float b) {
     return (uint32_t)__builtin_bit_cast(uint16_t, (bf16_t)a) | ((uint32_t)__builtin_bit_cast(uint16_t, (bf16_t)b) << 16);
   }
@@ -83,15 +87,46 @@ template <int L> __device__ __forceinline__ float dw_group_sum(float v) {
 }
 
 #ifndef GCV_DWR_ABLATE
-#define GCV_DWR_ABLATE 0   // diagnostics: 1 no tap FMAs, 2 no LN reduction, 4 no normalise/stores, 8 no input loads, 16 no barrier
+#define GCV_DWR_ABLATE 0   // diagnostics: 1 no tap FMAs, 2 no LN reduction, 4 no normalise/stores, 8 no input loads, 16 no barrier, 32 no priority rotation
+#endif
+#ifndef GCV_DW_STAMPS
+#define GCV_DW_STAMPS 0
+#endif
+#if GCV_DW_STAMPS
+// diagnostics (profiles/dw_stamps.py): s_memtime stamps of tap wave 0 (slots 0..7) and staging wave 0 (slots 8..15) of
+// workgroups 0..63 in the step GCV_DW_STAMP_IT; written to a buffer nothing else reads
+__device__ unsigned long long gcv_dw_stamps[64 * 32];
+#define GCV_DW_STAMP_IT 30
+#define DW_STAMP(cond, slot)                                                                    \
+  do {                                                                                          \
+    if ((cond) && blockIdx.x < 64) {                                                            \
+      unsigned long long _t;                                                                    \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");               \
+      gcv_dw_stamps[blockIdx.x * 32 + (slot)] = _t;                                             \
+    }                                                                                           \
+  } while (0)
+#else
+#define DW_STAMP(cond, slot) do { } while (0)
 #endif
 #define GCV_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// ---- inline-asm LDS reads of one staged (fp32) input row; the offsets are instruction immediates ----
+template <int OFF> __device__ __forceinline__ void dw_lds_rd(float& dst, uint32_t addr) {
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int C, int S, int S1> __device__ __forceinline__ void dw_read_row(float (&nxt)[13], uint32_t addr) {
+  if constexpr (S < S1) {
+    static_assert(S * C * 4 < 65536, "ds offset field");
+    dw_lds_rd<S * C * 4>(nxt[S], addr);
+    dw_read_row<C, S + 1, S1>(nxt, addr);
+  }
+}
 
 template <typename T, int C, int NS> struct DwRollLds {
   static constexpr int P = 7 * NS;
   static constexpr int HP = (NS == 1) ? 0 : 3;         // zero apron (pixels) left and right of a staged input row
   static constexpr int IN_ROW = (P + 2 * HP) * C;      // elements
-  static constexpr int IN_BYTES = 3 * IN_ROW * (int)sizeof(T);   // three-slot ring of staged input rows
+  static constexpr int IN_BYTES = 3 * IN_ROW * 4;      // three-slot ring of staged input rows, converted to fp32
   static constexpr int SVAL_BYTES = 2 * P * C * 4;
   static constexpr int bytes = IN_BYTES + SVAL_BYTES;
   static constexpr int NCONV = NS * C;                 // tap threads: one per (strip, channel)
@@ -116,7 +151,7 @@ dwconv7_ln_roll_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*
   constexpr int EPC = EL::EPC;
   constexpr int S0 = FULLW ? 3 : 0, S1 = FULLW ? 10 : 13;   // halo columns that can hold data
   extern __shared__ __attribute__((aligned(16))) unsigned char dwr_lds[];
-  T* const in_ring = reinterpret_cast<T*>(dwr_lds);
+  float* const in_ring = reinterpret_cast<float*>(dwr_lds);
   float* const sval_ring = reinterpret_cast<float*>(dwr_lds + LY::IN_BYTES);
 
   const int tid = threadIdx.x;
@@ -126,6 +161,7 @@ dwconv7_ln_roll_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*
   const int nrows = min(band_rows, H - ob);
   const int r0 = ob - 3;
   const int nit = nrows + 6;
+  const int it0 = max(0, -r0);                        // steps whose input row lies above the image are not run at all
   constexpr int row_bytes = W * C * (int)sizeof(T);
   const int64_t img_elems = (int64_t)H * W * C;
 
@@ -148,48 +184,88 @@ dwconv7_ln_roll_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*
     for (int i = 0; i < 7; ++i)
 #pragma unroll
       for (int j = 0; j < 7; ++j) acc[i][j] = bv;
-    const T* const in_base = in_ring + (sl * 7 + HP - 3) * C + c;
     float* const sv_base = sval_ring + sl * 7 * C + c;
+    // the 13 values of the NEXT input row are read from LDS while this row's FMAs run: inline-asm reads that nothing
+    // waits for until the `s_waitcnt lgkmcnt(0)` of the step's barrier, which names the registers so that no use can
+    // move above it.  (The ring holds fp32: 16-bit values would need 13 conversions and 13 more live registers here.)
+    float nxt[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) nxt[i] = 0.0f;
+    const uint32_t in_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)dwr_lds +
+                             (uint32_t)(((sl * 7 + HP - 3) * C + c) * 4);
+#define GCV_DW_BARRIER_NXT()                                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]),    \
+                 "+v"(nxt[4]), "+v"(nxt[5]), "+v"(nxt[6]), "+v"(nxt[7]), "+v"(nxt[8]), "+v"(nxt[9]), "+v"(nxt[10]), \
+                 "+v"(nxt[11]), "+v"(nxt[12])::"memory")
     GCV_LDS_BARRIER();                                 // P1: rows 0 and 1 are staged
-    int islot = 0;                                     // ring slot of input row `it` (it % 3)
+    dw_read_row<C, S0, S1>(nxt, in_addr);              // row it0 (slot 0)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt[4]), "+v"(nxt[5]),
+                 "+v"(nxt[6]), "+v"(nxt[7]), "+v"(nxt[8]), "+v"(nxt[9]), "+v"(nxt[10]), "+v"(nxt[11]), "+v"(nxt[12])::"memory");
+    int pslot = 1;                                     // ring slot of input row it + 1
     for (int base = 0; base < nit; base += 7) {
 #pragma unroll
       for (int ph = 0; ph < 7; ++ph) {
         const int it = base + ph;
-        if (it < nit) {
+        if (it >= it0 && it < nit) {
           const int r = r0 + it;
           float cur[13];
-          if (!(GCV_DWR_ABLATE & 1) && r >= 0 && r < H) {
-            const T* inr = in_base + islot * IN_ROW;
+          DW_STAMP(tid == 0 && it == GCV_DW_STAMP_IT, 0); DW_STAMP(tid == 320 && it == GCV_DW_STAMP_IT, 16); DW_STAMP(tid == NCONV - 64 && it == GCV_DW_STAMP_IT, 21);
 #pragma unroll
-            for (int s = S0; s < S1; ++s) cur[s] = EL::ld(inr + s * C);
-          }
-          islot = (islot == 2) ? 0 : islot + 1;
-          if (!(GCV_DWR_ABLATE & 1) && r >= 0 && r < H) {
-#pragma unroll
-            for (int ky = 0; ky < 7; ++ky) {
-              const int oi = it - ky;                  // output row (relative to the band) this tap row feeds
-              if (oi >= 0 && oi < nrows) {
-                const int slot = (ph - ky + 7) % 7;    // compile-time after unrolling
-#pragma unroll
-                for (int ox = 0; ox < 7; ++ox)
-#pragma unroll
-                  for (int kx = 0; kx < 7; ++kx)
-                    if (ox + kx >= S0 && ox + kx < S1)
-                      acc[slot][ox] = fmaf(cur[ox + kx], w[ky * 7 + kx], acc[slot][ox]);
+          for (int s = S0; s < S1; ++s) cur[s] = nxt[s];
+          if (!(GCV_DWR_ABLATE & 1)) dw_read_row<C, S0, S1>(nxt, in_addr + (uint32_t)(pslot * IN_ROW * 4));
+          pslot = (pslot == 2) ? 0 : pslot + 1;
+          // tap rows in the order 6, 0, 1 .. 5: row 6 completes an output row, which is written to LDS at once so that
+          // the 84 ds_write_b32 of the workgroup (64 B/clk: ~340 cycles) drain under the other six rows' FMAs
+          const bool rvalid = !(GCV_DWR_ABLATE & 1) && r >= 0 && r < H;
+          auto tap_row = [&](int ky, int pos) {
+            const int oi = it - ky;                    // output row (relative to the band) this tap row feeds
+            if (rvalid && oi >= 0 && oi < nrows) {
+              const int slot = (ph - ky + 7) % 7;      // compile-time after unrolling
+              // Three tap waves share a SIMD, and its arbiter (priority, then age) lets the two oldest issue at their
+              // full rate while the third waits, then leaves that one to run ALONE at half the SIMD's rate
+              // (profiles/micro/fmac_banks.hip: 3 waves/SIMD take the time of 4).  Falling priority as a wave
+              // advances through its seven tap rows keeps the three within a row of each other instead.
+              if (!(GCV_DWR_ABLATE & 32)) {
+                switch (pos) {                         // (the builtin wants a literal; the switch folds after unrolling)
+                  case 0: case 1: __builtin_amdgcn_s_setprio(3); break;
+                  case 2: case 3: __builtin_amdgcn_s_setprio(2); break;
+                  case 4: case 5: __builtin_amdgcn_s_setprio(1); break;
+                  default: __builtin_amdgcn_s_setprio(0); break;
+                }
               }
+#pragma unroll
+              for (int ox = 0; ox < 7; ++ox)
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx)
+                  if (ox + kx >= S0 && ox + kx < S1)
+                    acc[slot][ox] = fmaf(cur[ox + kx], w[ky * 7 + kx], acc[slot][ox]);
             }
-          }
+          };
+          tap_row(6, 0);
           if (it >= 6) {                               // input row r completes output row r - 3
             const int sd = (ph + 1) % 7;
             float* sv = sv_base + (it & 1) * (P * C);
 #pragma unroll
             for (int j = 0; j < 7; ++j) { sv[j * C] = acc[sd][j]; acc[sd][j] = bv; }
           }
-          if (!(GCV_DWR_ABLATE & 16)) GCV_LDS_BARRIER();
+#pragma unroll
+          for (int ky = 0; ky < 6; ++ky) tap_row(ky, ky + 1);
+#if GCV_DW_STAMPS
+          asm volatile("" : "+v"(acc[0][0]), "+v"(acc[1][0]), "+v"(acc[2][0]), "+v"(acc[3][0]), "+v"(acc[4][0]), "+v"(acc[5][0]), "+v"(acc[6][0]));
+          DW_STAMP(tid == 0 && it == GCV_DW_STAMP_IT, 2); DW_STAMP(tid == 320 && it == GCV_DW_STAMP_IT, 18); DW_STAMP(tid == NCONV - 64 && it == GCV_DW_STAMP_IT, 23);
+#endif
+          DW_STAMP(tid == 0 && it == GCV_DW_STAMP_IT, 3); DW_STAMP(tid == 320 && it == GCV_DW_STAMP_IT, 19); DW_STAMP(tid == NCONV - 64 && it == GCV_DW_STAMP_IT, 24);
+          if (!(GCV_DWR_ABLATE & 16)) GCV_DW_BARRIER_NXT();
+          DW_STAMP(tid == 0 && it == GCV_DW_STAMP_IT, 4); DW_STAMP(tid == 320 && it == GCV_DW_STAMP_IT, 20); DW_STAMP(tid == NCONV - 64 && it == GCV_DW_STAMP_IT, 25);
+#if GCV_DW_STAMPS
+          if (tid == 0 && blockIdx.x < 64 && (it == GCV_DW_STAMP_IT || it == GCV_DW_STAMP_IT + 10))
+            gcv_dw_stamps[blockIdx.x * 32 + (it == GCV_DW_STAMP_IT ? 5 : 7)] = __builtin_amdgcn_s_memrealtime();
+          DW_STAMP(tid == 0 && it == GCV_DW_STAMP_IT + 10, 6);
+#endif
         }
       }
     }
+#undef GCV_DW_BARRIER_NXT
   } else {
     // ================================================================== staging + LayerNorm waves
     __builtin_amdgcn_s_setprio(3);                     // one latency-bound wave per SIMD beside three FMA-bound ones
@@ -214,11 +290,11 @@ dwconv7_ln_roll_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*
     }
     // zero the aprons of the three ring slots once (they are never written again)
     if constexpr (HP > 0) {
-      constexpr int APR = HP * C / EPC;                // pieces per apron
+      constexpr int APR = HP * C / 4;                  // float4 pieces per apron
       for (int i = lid; i < 6 * APR; i += NLN) {
         const int slot = i / (2 * APR), j = i - slot * (2 * APR);
-        const int off = slot * IN_ROW + (j < APR ? j * EPC : (HP + P) * C + (j - APR) * EPC);
-        *reinterpret_cast<u32x4*>(in_ring + off) = u32x4{0u, 0u, 0u, 0u};
+        const int off = slot * IN_ROW + (j < APR ? j * 4 : (HP + P) * C + (j - APR) * 4);
+        *reinterpret_cast<float4*>(in_ring + off) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       }
     }
     u32x4 stg[NPT];
@@ -229,11 +305,21 @@ dwconv7_ln_roll_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*
         if (NPT * NLN == ROWP || lid + k * NLN < ROWP)
           stg[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, (lid + k * NLN) * 16, row * row_bytes, 0));
     };
-    auto stage_write = [&](int slot) {
+    auto stage_write = [&](int slot) {                 // 16-bit storage is widened to fp32 on the way into the ring
 #pragma unroll
       for (int k = 0; k < NPT; ++k)
-        if (NPT * NLN == ROWP || lid + k * NLN < ROWP)
-          *reinterpret_cast<u32x4*>(in_ring + slot * IN_ROW + HP * C + (lid + k * NLN) * EPC) = stg[k];
+        if (NPT * NLN == ROWP || lid + k * NLN < ROWP) {
+          float* dst = in_ring + slot * IN_ROW + HP * C + (lid + k * NLN) * EPC;
+          if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<u32x4*>(dst) = stg[k];
+          } else {
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { f[2 * e] = EL::lo(stg[k][e]); f[2 * e + 1] = EL::hi(stg[k][e]); }
+            *reinterpret_cast<float4*>(dst) = make_float4(f[0], f[1], f[2], f[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(f[4], f[5], f[6], f[7]);
+          }
+        }
     };
     // LayerNorm + store of one finished output row: every lane keeps its 24 values in registers
     auto ln_row = [&](int orow, int slot) {
@@ -245,6 +331,11 @@ dwconv7_ln_roll_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*
         const float4 a = *reinterpret_cast<const float4*>(sv + 4 * L * j);
         v[4 * j] = a.x; v[4 * j + 1] = a.y; v[4 * j + 2] = a.z; v[4 * j + 3] = a.w;
       }
+#if GCV_DW_STAMPS
+#pragma unroll
+      for (int e = 0; e < 24; ++e) asm volatile("" : "+v"(v[e]));
+      DW_STAMP(lid == 0 && orow == ob + GCV_DW_STAMP_IT - 7, 11);
+#endif
       float mean, rstd;
       if constexpr (sizeof(T) == 4) {                  // fp32 storage: two-pass statistics (local mean / M2, Chan's combination)
         float s = 0.0f;
@@ -269,6 +360,10 @@ dwconv7_ln_roll_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*
         const float ex2 = dw_group_sum<L>(q0 + q1) * (1.0f / C);
         rstd = __builtin_amdgcn_rsqf(fmaxf(fmaf(-mean, mean, ex2), 0.0f) + eps);
       }
+#if GCV_DW_STAMPS
+      asm volatile("" : "+v"(rstd), "+v"(mean));
+      DW_STAMP(lid == 0 && orow == ob + GCV_DW_STAMP_IT - 7, 12);
+#endif
       if (GCV_DWR_ABLATE & 4) return;
       // all six pieces are finished in registers of their own BEFORE the first store is issued: a 16-byte store whose
       // data registers the very next VALU instructions overwrite came out with a stale first dword in lanes 12-15 of
@@ -303,17 +398,22 @@ dwconv7_ln_roll_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*
       __builtin_amdgcn_sched_barrier(0);
     };
 
-    if (row_ok(0)) { stage_load(0); stage_write(0); }
-    if (row_ok(1)) { stage_load(1); stage_write(1); }
-    if (!(GCV_DWR_ABLATE & 8) && row_ok(2)) stage_load(2);
+    if (row_ok(it0)) { stage_load(it0); stage_write(0); }
+    if (row_ok(it0 + 1)) { stage_load(it0 + 1); stage_write(1); }
+    if (!(GCV_DWR_ABLATE & 8) && row_ok(it0 + 2)) stage_load(it0 + 2);
     GCV_LDS_BARRIER();                                 // P1
-    int wslot = 2;                                     // ring slot row it + 2 goes to ((it + 2) % 3)
-    for (int it = 0; it < nit; ++it) {
+    int wslot = 2;                                     // ring slot row it + 2 goes to ((it - it0 + 2) % 3)
+    for (int it = it0; it < nit; ++it) {
+      DW_STAMP(lid == 0 && it == GCV_DW_STAMP_IT, 8); DW_STAMP(lid == NLN - 64 && it == GCV_DW_STAMP_IT, 26);
       if (!(GCV_DWR_ABLATE & 8) && row_ok(it + 2)) stage_write(wslot);
       wslot = (wslot == 2) ? 0 : wslot + 1;
+      DW_STAMP(lid == 0 && it == GCV_DW_STAMP_IT, 9);
       if (!(GCV_DWR_ABLATE & 8) && row_ok(it + 3)) stage_load(it + 3);
+      DW_STAMP(lid == 0 && it == GCV_DW_STAMP_IT, 10);
       if (!(GCV_DWR_ABLATE & 2) && it >= 7) ln_row(ob + it - 7, (it - 1) & 1);
+      DW_STAMP(lid == 0 && it == GCV_DW_STAMP_IT, 13); DW_STAMP(lid == NLN - 64 && it == GCV_DW_STAMP_IT, 27);
       if (!(GCV_DWR_ABLATE & 16)) GCV_LDS_BARRIER();
+      DW_STAMP(lid == 0 && it == GCV_DW_STAMP_IT, 14); DW_STAMP(lid == NLN - 64 && it == GCV_DW_STAMP_IT, 28);
     }
     if (!(GCV_DWR_ABLATE & 2)) ln_row(ob + nit - 7, (nit - 1) & 1);
   }
