@@ -138,7 +138,7 @@ template <typename T, int C, int NS> struct DwRollLds {
 // output rows).  Waves are specialised: threads [0, NS * C) run the taps, the last third stages input rows and does
 // LayerNorm + the stores of the row the tap waves finished one step earlier; the two meet at one barrier per row.
 template <typename T, int C, int NS>
-__global__ void __launch_bounds__((DwRollLds<T, C, NS>::NT), (DwRollLds<T, C, NS>::NT == 1024 ? 4 : 2))
+__global__ void __launch_bounds__((DwRollLds<T, C, NS>::NT), 4)
 dwconv7_ln_roll_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*[49][C]*/,
                        const float* __restrict__ bdw, const float* __restrict__ lnw, const float* __restrict__ lnb,
                        T* __restrict__ y, int H, int band_rows, int nbands, float eps) {

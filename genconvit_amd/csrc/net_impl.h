@@ -532,11 +532,17 @@ template <typename T> struct NetImpl : NetBase {
       }
       for (int j = 0; j < kDepths[i]; ++j, ++bi) {
         const CnxBlockW<T>& k = w.blk[bi];
-        for (int s = 0; s < nseg; ++s) {
-          GCV_TRY(run("cnx.dwconv7_ln", 2.0 * 49 * m[s] * C, 2.0 * sizeof(T) * (double)m[s] * C + 49.0 * C * 4, [&] {
-            return launch_dwconv7_ln<T>(X + moff[s] * C, k.dw_w, k.dw_b, k.ln_w, k.ln_b, Y + moff[s] * C, segs[s].n,
-                                        h[s], wd[s], C, 1e-6f, cur, k.dw_wpk);
+        for (int s = 0; s < nseg;) {
+          // neighbouring segments of one geometry (ED: reconstruction + original pass) are contiguous in the token
+          // buffer: one launch over all their images (256 images fill the 256 CUs with whole-image row bands)
+          int e = s + 1, nimg = segs[s].n;
+          int64_t mm = m[s];
+          while (e < nseg && h[e] == h[s] && wd[e] == wd[s]) { nimg += segs[e].n; mm += m[e]; ++e; }
+          GCV_TRY(run("cnx.dwconv7_ln", 2.0 * 49 * mm * C, 2.0 * sizeof(T) * (double)mm * C + 49.0 * C * 4, [&] {
+            return launch_dwconv7_ln<T>(X + moff[s] * C, k.dw_w, k.dw_b, k.ln_w, k.ln_b, Y + moff[s] * C, nimg, h[s],
+                                        wd[s], C, 1e-6f, cur, k.dw_wpk);
           }));
+          s = e;
         }
         if constexpr (sizeof(T) == 2) {
           if (k.fc2_wc && use_fused_mlp && (C < 384 || use_fused_mlp384)) {

@@ -34,6 +34,17 @@ template <int MODE> __global__ void k(long long* cyc, float* out) {
   } else if (MODE == 4) {  // what hipcc emitted for the dw kernel: consecutive acc, consecutive a, one b
     LOOP(REP8("v_fmac_f32 v8, v40, v52\n v_fmac_f32 v9, v41, v52\n v_fmac_f32 v10, v42, v52\n v_fmac_f32 v11, v43, v52\n"
               "v_fmac_f32 v12, v44, v52\n v_fmac_f32 v13, v45, v52\n v_fmac_f32 v14, v46, v52\n v_fmac_f32 v8, v41, v53\n"));
+  } else if (MODE == 10 || MODE == 11 || MODE == 12) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (MODE == 10) {           // static priority by position on the SIMD (waves w, w+4, w+8 share one)
+      if (wave >= 8) __builtin_amdgcn_s_setprio(0); else if (wave >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
+    }
+    if (MODE == 12) {           // younger waves get the HIGHER priority
+      if (wave >= 8) __builtin_amdgcn_s_setprio(2); else if (wave >= 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    }
+    if (MODE == 11 && wave >= 12) return;   // 1024-thread launch: three busy waves and one that has left per SIMD
+    LOOP(REP8("v_fmac_f32 v8, v40, v52\n v_fmac_f32 v9, v41, v52\n v_fmac_f32 v10, v42, v52\n v_fmac_f32 v11, v43, v52\n"
+              "v_fmac_f32 v12, v44, v52\n v_fmac_f32 v13, v45, v52\n v_fmac_f32 v14, v46, v52\n v_fmac_f32 v8, v41, v53\n"));
   } else if (MODE == 5) {  // scalar b operand (tap in an SGPR): two VGPR reads only
     LOOP(REP8("v_fmac_f32 v8, s4, v40\n v_fmac_f32 v9, s4, v41\n v_fmac_f32 v10, s4, v42\n v_fmac_f32 v11, s4, v43\n"
               "v_fmac_f32 v12, s5, v44\n v_fmac_f32 v13, s5, v45\n v_fmac_f32 v14, s5, v46\n v_fmac_f32 v15, s5, v41\n"));
@@ -54,16 +65,17 @@ template <int MODE> __global__ void k(long long* cyc, float* out) {
   }
   long long t1 = __builtin_amdgcn_s_memtime();
   if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
-  if (out) out[0] = 0.f;
+  if (out && blockIdx.x == 0 && (threadIdx.x & 63) == 0) out[threadIdx.x >> 6] = (float)(t1 - t0);
 }
 
 template <int MODE> void run(const char* name) {
   long long* cyc; hipMalloc(&cyc, 8);
+  float* outd; hipMalloc(&outd, 64);
   for (int threads : {256, 512, 768, 1024}) {
-    hipLaunchKernelGGL((k<MODE>), dim3(256), dim3(threads), 0, 0, cyc, nullptr);
+    hipLaunchKernelGGL((k<MODE>), dim3(256), dim3(threads), 0, 0, cyc, outd);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, 0);
-    for (int r = 0; r < 10; ++r) hipLaunchKernelGGL((k<MODE>), dim3(256), dim3(threads), 0, 0, cyc, nullptr);
+    for (int r = 0; r < 10; ++r) hipLaunchKernelGGL((k<MODE>), dim3(256), dim3(threads), 0, 0, cyc, outd);
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
@@ -72,11 +84,20 @@ template <int MODE> void run(const char* name) {
     const double wps = threads / 256.0;
     printf("%-44s %d waves/SIMD: %6.2f ticks per instr per wave | wall %7.1f us -> %5.2f ns per instr per SIMD\n", name,
            (int)wps, h / n, ms * 1e3, ms * 1e6 / (n * wps));
+    float pw[16]; hipMemcpy(pw, outd, sizeof(pw), hipMemcpyDeviceToHost);
+    printf("      per-wave ticks per instr (block 0):");
+    for (int w = 0; w < threads / 64; ++w) printf(" %.2f", pw[w] / n);
+    printf("\n");
   }
   hipFree(cyc);
 }
 
 int main() {
+  run<4>("v_fmac_f32 hipcc-like (consecutive regs)");
+  run<10>("hipcc-like, priority 2/1/0 by wave age");
+  run<12>("hipcc-like, priority 0/1/2 by wave age");
+  run<11>("hipcc-like, waves 12-15 exit at once");
+  return 0;
   run<0>("v_fmac_f32 acc/a/b in banks 0/1/2");
   run<1>("v_fmac_f32 a,b same bank");
   run<2>("v_fmac_f32 acc,a same bank");
