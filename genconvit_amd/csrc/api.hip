@@ -203,24 +203,7 @@ int gcv_k_stem_ln(int dtype, const void* x, int64_t sb, int64_t sc, int64_t sy, 
 
 int gcv_k_dwconv7_ln(int dtype, const void* x, const float* wdw, const float* bdw, const float* lnw,
                      const float* lnb, void* y, int nimg, int H, int W, int C, float eps, gcv_stream s) {
-  if (dtype == GCV_F32)
-    return launch_dwconv7_ln<float>((const float*)x, wdw, bdw, lnw, lnb, (float*)y, nimg, H, W, C, eps, (hipStream_t)s);
-  // 16-bit storage: the taps are packed to 16-bit pairs first, as the network does once at load time (net_impl.h)
-  GCV_REQUIRE(dtype == GCV_F16 || dtype == GCV_BF16, "bad dtype code");
-  GCV_REQUIRE(C > 0 && C % 4 == 0, "dwconv: C must be a multiple of 4");
-  uint32_t* wpk = nullptr;
-  GCV_CHECK_HIP(hipMalloc((void**)&wpk, (size_t)28 * C * 4));
-  int rc;
-  if (dtype == GCV_F16) {
-    rc = launch_pack_dw_taps<half_t>(wdw, wpk, C, (hipStream_t)s);
-    if (!rc) rc = launch_dwconv7_ln<half_t>((const half_t*)x, wdw, bdw, lnw, lnb, (half_t*)y, nimg, H, W, C, eps, (hipStream_t)s, wpk);
-  } else {
-    rc = launch_pack_dw_taps<bf16_t>(wdw, wpk, C, (hipStream_t)s);
-    if (!rc) rc = launch_dwconv7_ln<bf16_t>((const bf16_t*)x, wdw, bdw, lnw, lnb, (bf16_t*)y, nimg, H, W, C, eps, (hipStream_t)s, wpk);
-  }
-  (void)hipStreamSynchronize((hipStream_t)s);
-  (void)hipFree(wpk);
-  return rc;
+  DISPATCH_DT(dtype, launch_dwconv7_ln<T>((const T*)x, wdw, bdw, lnw, lnb, (T*)y, nimg, H, W, C, eps, (hipStream_t)s));
 }
 
 int gcv_k_ln_patchify(int dtype, const void* x, const float* w, const float* b, void* out, int nimg, int H, int W,

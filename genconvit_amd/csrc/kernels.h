@@ -19,16 +19,14 @@ namespace gcv {
 template <typename T> int launch_stem_ln(const T* x, int64_t sb, int64_t sc, int64_t sy, int64_t sx, const float* wp,
                                          const float* bias, const float* lnw, const float* lnb, T* out, int nimg,
                                          int Ho, int Wo, float eps, hipStream_t s);
-// wpk: optional pre-packed taps for the 16-bit C = 96 / 192 kernel (launch_pack_dw_taps), nullptr = pack per tile
 template <typename T> int launch_dwconv7_ln(const T* x, const float* wdw, const float* bdw, const float* lnw,
                                             const float* lnb, T* y, int nimg, int H, int W, int C, float eps,
-                                            hipStream_t s, const uint32_t* wpk = nullptr);
+                                            hipStream_t s);
 // rolling-strip variant (dwconv_roll.h): W % 7 == 0 shapes of ConvNeXt-T; `applicable` says whether it covers a shape
 template <typename T> bool dwconv_roll_applicable(int H, int W, int C);
 template <typename T> int launch_dwconv7_ln_roll(const T* x, const float* wdw, const float* bdw, const float* lnw,
                                                  const float* lnb, T* y, int nimg, int H, int W, int C, float eps,
                                                  hipStream_t s);
-template <typename T> int launch_pack_dw_taps(const float* wdw, uint32_t* out, int C, hipStream_t s);
 template <typename T> int launch_ln_patchify(const T* x, const float* w, const float* b, T* out, int nimg, int H,
                                              int W, int C, float eps, hipStream_t s);
 template <typename T> int launch_layernorm_rows(const T* x, const float* w, const float* b, T* out, int64_t rows,

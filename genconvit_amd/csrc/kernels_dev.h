@@ -144,7 +144,9 @@ __global__ void __launch_bounds__(256) stem_ln_kernel(const T* __restrict__ x, i
   }
 }
 
-// ------------------------------------------------------------------ K4: dwconv7x7 + LN
+// ------------------------------------------------------------------ K4: dwconv7x7 + LN (generic tile kernel)
+// The ConvNeXt-T shapes with W % 7 == 0 run the rolling-strip kernel of dwconv_roll.h; this one covers the rest
+// (the 3x3 map of the 112-px pass).
 // NHWC.  One thread per channel of a 7x7 output tile: the 49 taps of that channel live in
 // registers, every input value of the 13x13 halo window is loaded once (lanes = consecutive
 // channels -> coalesced) and scattered into the <=49 accumulators it touches.  LayerNorm over
@@ -272,362 +274,6 @@ dwconv7_ln_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*[49][
         yb[((int64_t)oy * W + ox) * C] = from_f<T>((acc[p] - mean) * rstd * lw + lb);
       }
     }
-  }
-}
-
-// ------------------------------------------------------------------ K4 (16-bit): packed-pair helpers
-// horizontally adjacent inputs / taps are packed in pairs and multiplied by v_dot2c_f32_{f16,bf16} (2 MACs per
-// instruction, fp32 accumulate; taps rounded to the storage dtype)
-template <typename T> struct Dot2;
-template <> struct Dot2<half_t> {
-  typedef _Float16 v2 __attribute__((ext_vector_type(2)));
-  __device__ static __forceinline__ float run(uint32_t a, uint32_t b, float c) {
-    return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), c, false);
-  }
-};
-template <> struct Dot2<bf16_t> {
-  typedef __bf16 v2 __attribute__((ext_vector_type(2)));
-  __device__ static __forceinline__ float run(uint32_t a, uint32_t b, float c) {
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), c, false);
-  }
-};
-
-
-// taps (49, C) fp32 -> [28][C] dwords of packed 16-bit pairs (tap(ky,2j), tap(ky,2j+1)), tap(ky,7) = 0: the LDS image
-// the v3 kernel works from.  Built once when the weights are loaded (per tile it cost 11 % of the C=96 kernel).
-template <typename T>
-__global__ void __launch_bounds__(256) pack_dw_taps_kernel(const float* __restrict__ wdw, uint32_t* __restrict__ out, int C) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 28 * C) return;
-  const int c = i % C, kj = i / C;
-  const int ky = kj >> 2, j = kj & 3;
-  const uint32_t lo = bits16<T>(wdw[(ky * 7 + 2 * j) * C + c]);
-  const uint32_t hi = (j < 3) ? bits16<T>(wdw[(ky * 7 + 2 * j + 1) * C + c]) : 0u;
-  out[i] = lo | (hi << 16);
-}
-
-// ------------------------------------------------------------------ K4 (16-bit, C = 384 / 768): packed-pair taps
-// Same decomposition as dwconv7_ln_kernel (one thread per channel of a 7x7 tile, inputs straight from global,
-// coalesced over channels), but the 49 fp32 taps become 28 pre-packed 16-bit pairs and the MACs v_dot2c: ~140 VGPRs
-// instead of 229, so the CU holds three waves per SIMD — two 6-wave workgroups at C = 384 instead of one.
-template <typename T, int C>
-__global__ void __launch_bounds__(C, 3)
-dwconv7_ln_pk_kernel(const T* __restrict__ x, const uint32_t* __restrict__ wpk /*[28][C]*/, const float* __restrict__ bdw,
-                     const float* __restrict__ lnw, const float* __restrict__ lnb, T* __restrict__ y, int nimg, int H,
-                     int W, float eps) {
-  static_assert(sizeof(T) == 2 && (C == 384 || C == 768), "packed-tap variant: 16-bit storage, C = 384 / 768");
-  extern __shared__ __attribute__((aligned(16))) float dwp_lds[];  // [49][C] values, then [49][2] stats
-  float* stats = dwp_lds + 49 * C;
-
-  const int tid = threadIdx.x;
-  const int c = tid;
-  const int tiles_x = (W + 6) / 7, tiles_y = (H + 6) / 7;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tx = tile % tiles_x, t2 = tile / tiles_x;
-  const int ty = t2 % tiles_y, b = t2 / tiles_y;
-  const int x0 = tx * 7, y0 = ty * 7;
-
-  uint32_t w2[28];
-#pragma unroll
-  for (int k = 0; k < 28; ++k) w2[k] = wpk[k * C + c];
-  const float bv = bdw[c];
-  float acc[49];
-#pragma unroll
-  for (int t = 0; t < 49; ++t) acc[t] = bv;
-
-  const unsigned short* xb = reinterpret_cast<const unsigned short*>(x) + (int64_t)b * H * W * C + c;
-  int xoff[13];
-  uint32_t xmask[13];
-#pragma unroll
-  for (int s = 0; s < 13; ++s) {
-    const int ix = x0 + s - 3;
-    xmask[s] = (ix >= 0 && ix < W) ? 0xffffu : 0u;
-    xoff[s] = min(max(ix, 0), W - 1) * C;
-  }
-  // halo rows in batches of RB, software-pipelined: the 13*RB two-byte loads of batch i+1 are issued before the taps
-  // of batch i run, so a thread waits for global memory once, not once per batch
-  constexpr int RB = 2;
-  constexpr int NBATCH = (13 + RB - 1) / RB;
-  uint32_t raw[2][RB][14];
-  auto load_batch = [&](int rb, uint32_t (&dst)[RB][14]) {
-#pragma unroll
-    for (int rr = 0; rr < RB; ++rr) {
-      const int r = rb + rr;
-      if (r < 13) {
-        const int iy = y0 + r - 3;
-        const uint32_t rmask = (iy >= 0 && iy < H) ? 0xffffu : 0u;
-        const unsigned short* rp = xb + (int64_t)min(max(iy, 0), H - 1) * W * C;
-#pragma unroll
-        for (int s = 0; s < 13; ++s) dst[rr][s] = (uint32_t)rp[xoff[s]] & (rmask & xmask[s]);
-        dst[rr][13] = 0u;
-      }
-    }
-  };
-  load_batch(0, raw[0]);
-#pragma unroll
-  for (int bi = 0; bi < NBATCH; ++bi) {
-    const int rb = bi * RB;
-    if (bi + 1 < NBATCH) load_batch(rb + RB, raw[(bi + 1) & 1]);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int rr = 0; rr < RB; ++rr) {
-      const int r = rb + rr;
-      if (r < 13) {
-        uint32_t pp[13];
-#pragma unroll
-        for (int s = 0; s < 13; ++s) pp[s] = raw[bi & 1][rr][s] | (raw[bi & 1][rr][s + 1] << 16);
-#pragma unroll
-        for (int ky = 0; ky < 7; ++ky) {
-          const int oy = r - ky;
-          if (oy >= 0 && oy < 7) {
-#pragma unroll
-            for (int ox = 0; ox < 7; ++ox)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) acc[oy * 7 + ox] = Dot2<T>::run(pp[ox + 2 * j], w2[ky * 4 + j], acc[oy * 7 + ox]);
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma unroll
-  for (int p = 0; p < 49; ++p) dwp_lds[p * C + c] = acc[p];
-  __syncthreads();
-
-  const int grp = tid >> 5, gl = tid & 31;
-  constexpr int NG = C / 32;
-  for (int p = grp; p < 49; p += NG) {
-    const float* row = dwp_lds + p * C;
-    float rv[C / 32];                                // the pixel's values stay in registers for both passes
-    float s = 0.0f;
-#pragma unroll
-    for (int k = 0; k < C / 32; ++k) { rv[k] = row[gl + 32 * k]; s += rv[k]; }
-    s = group32_sum(s);
-    const float mean = s * (1.0f / C);
-    float q = 0.0f;
-#pragma unroll
-    for (int k = 0; k < C / 32; ++k) { const float d = rv[k] - mean; q = fmaf(d, d, q); }
-    q = group32_sum(q);
-    if (gl == 0) {
-      stats[2 * p] = mean;
-      stats[2 * p + 1] = 1.0f / sqrtf(q * (1.0f / C) + eps);
-    }
-  }
-  __syncthreads();
-
-  const float lw = lnw[c], lb = lnb[c];
-  T* yb = y + (int64_t)b * H * W * C + c;
-#pragma unroll
-  for (int p = 0; p < 49; ++p) {
-    const int oy = y0 + p / 7, ox = x0 + p % 7;
-    if (oy < H && ox < W)
-      yb[((int64_t)oy * W + ox) * C] = from_f<T>((acc[p] - stats[2 * p]) * stats[2 * p + 1] * lw + lb);
-  }
-}
-
-#ifndef GCV_DW_ABLATE
-#define GCV_DW_ABLATE 0     // diagnostics: 1 one tap row, 2 no LN stats, 4 no tap packing, 8 no halo loads, 16 no stores
-#endif
-// ------------------------------------------------------------------ K4 v3 (16-bit, C = 96 / 192)
-// Occupancy-first decomposition of the same op: one workgroup = one 7x7 tile, one THREAD = one channel of RPT
-// output rows (7 x RPT accumulators): 384 threads per tile at C = 96 (RPT = 2, three workgroups per CU), 768 at
-// C = 192 (two per CU), instead of one thread per channel with 49 accumulators.  The 13x13 halo window (all C
-// channels) is staged in LDS by 16-byte coalesced loads (zero fill outside the image); taps live in LDS as packed
-// pairs [28][C], pre-packed at weight-load time (`wpk`; packing them per tile cost 11 % of the kernel); MACs by
-// v_dot2c (fp32 accumulate); LayerNorm statistics by 32-lane group reductions over an LDS [pixel][C] image; the
-// normalised tile is written with 16-byte stores.  Phase costs at C = 96, 256 images (GCV_DW_ABLATE builds): taps +
-// LN 163 us, halo loads 45, tap packing 37 (gone with wpk), stores 9, launch / barrier skeleton 82 of 335.
-template <typename T, int C, int RPT, bool DOT2>
-__global__ void __launch_bounds__(((7 + RPT - 1) / RPT) * C)
-dwconv7_ln_v3_kernel(const T* __restrict__ x, const float* __restrict__ wdw, const float* __restrict__ bdw,
-                     const float* __restrict__ lnw, const float* __restrict__ lnb, T* __restrict__ y, int nimg, int H,
-                     int W, float eps, const uint32_t* __restrict__ wpk) {
-  static_assert(sizeof(T) == 2 && (C == 96 || C == 192), "v3 covers 16-bit storage, C = 96 / 192");
-  constexpr int NRG = (7 + RPT - 1) / RPT;            // row groups (threads per channel)
-  constexpr int NT = NRG * C;
-  constexpr int CP = C / 8;                           // 16-byte pieces per pixel
-  constexpr int IN_BYTES = 169 * C * 2;
-  constexpr int STAT_OFF = 49 * C * 4;
-  constexpr int OUT_OFF = (STAT_OFF + 49 * 8 + 255) & ~255;
-  static_assert(OUT_OFF + 49 * C * 2 <= IN_BYTES, "LN / output staging must fit in the halo window");
-  extern __shared__ __attribute__((aligned(16))) unsigned char dw3_lds[];
-  unsigned short* sIn = reinterpret_cast<unsigned short*>(dw3_lds);
-  float* sval = reinterpret_cast<float*>(dw3_lds);
-  float* stats = reinterpret_cast<float*>(dw3_lds + STAT_OFF);
-  unsigned short* sOut = reinterpret_cast<unsigned short*>(dw3_lds + OUT_OFF);
-  constexpr bool W_IN_LDS = (C == 96);                 // C=192: taps straight from global so two tiles fit a CU
-  uint32_t* sW2 = reinterpret_cast<uint32_t*>(dw3_lds + IN_BYTES);     // [28][C] packed tap pairs
-
-  const int tid = threadIdx.x;
-  const int tiles_x = (W + 6) / 7, tiles_y = (H + 6) / 7;
-  // XCD-aware order: blocks are dealt round-robin over the 8 XCDs, so give every XCD a contiguous run of
-  // tiles (whole images): neighbouring tiles then find their shared halo in that XCD's L2 instead of
-  // re-fetching it through the fabric (the 13x13 window is 3.45x the 7x7 core)
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tx = tile % tiles_x, t2 = tile / tiles_x;
-  const int ty = t2 % tiles_y, b = t2 / tiles_y;
-  const int x0 = tx * 7, y0 = ty * 7;
-  const int64_t img = (int64_t)b * H * W;
-
-  // ---- taps -> LDS as (tap(ky,2j), tap(ky,2j+1)) pairs, tap(ky,7) = 0 ----
-  if (W_IN_LDS && wpk) {                               // pre-packed taps: 28*C dwords = one 16-byte piece per thread
-    for (int i = tid; i < 28 * C / 4; i += NT) *(u32x4*)(sW2 + 4 * i) = *(const u32x4*)(wpk + 4 * i);
-  }
-  for (int i = tid; W_IN_LDS && !wpk && !(GCV_DW_ABLATE & 4) && i < 28 * C; i += NT) {
-    const int c = i % C, kj = i / C;
-    const int ky = kj >> 2, j = kj & 3;
-    const uint32_t lo = bits16<T>(wdw[(ky * 7 + 2 * j) * C + c]);
-    const uint32_t hi = (j < 3) ? bits16<T>(wdw[(ky * 7 + 2 * j + 1) * C + c]) : 0u;
-    sW2[i] = lo | (hi << 16);
-  }
-  // ---- halo window -> LDS (independent 16-byte loads, zero outside the image) ----
-  constexpr int NPIECE = 169 * CP;
-  constexpr int NIT = (NPIECE + NT - 1) / NT;
-  {
-    u32x4 v[NIT];
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int idx = tid + i * NT;
-      const int pix = idx / CP, pc = idx - pix * CP;
-      const int r = pix / 13, sx = pix - r * 13;
-      const int iy = y0 + r - 3, ix = x0 + sx - 3;
-      const bool ok = idx < NPIECE && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      const int64_t off = ok ? ((img + (int64_t)iy * W + ix) * C + 8 * pc) : 0;
-      const u32x4 t = (GCV_DW_ABLATE & 8) ? u32x4{(uint32_t)idx, 1u, 2u, 3u} : *(const u32x4*)(x + off);
-      const uint32_t m = ok ? 0xffffffffu : 0u;
-      v[i] = u32x4{t[0] & m, t[1] & m, t[2] & m, t[3] & m};
-    }
-#pragma unroll
-    for (int i = 0; i < NIT; ++i) {
-      const int idx = tid + i * NT;
-      if (idx < NPIECE) *(u32x4*)(sIn + idx * 8) = v[i];
-    }
-  }
-  __syncthreads();
-
-  // ---- 7x7 taps: thread = (row group rg, channel c) ----
-  const int rg = tid / C, c = tid - rg * C;
-  const int oy0 = rg * RPT;
-  float acc[RPT][7];
-  const float bv = bdw[c];
-#pragma unroll
-  for (int rr = 0; rr < RPT; ++rr)
-#pragma unroll
-    for (int ox = 0; ox < 7; ++ox) acc[rr][ox] = bv;
-#ifndef GCV_DW_ABLATE
-#define GCV_DW_ABLATE 0
-#endif
-  if (DOT2) {
-    uint32_t w2[28];
-#pragma unroll
-    for (int k = 0; k < 28; ++k) {
-      if (W_IN_LDS) {
-        w2[k] = sW2[k * C + c];
-      } else if (wpk) {
-        w2[k] = wpk[k * C + c];
-      } else {
-        const int ky = k >> 2, j = k & 3;
-        const uint32_t lo = bits16<T>(wdw[(ky * 7 + 2 * j) * C + c]);
-        const uint32_t hi = (j < 3) ? bits16<T>(wdw[(ky * 7 + 2 * j + 1) * C + c]) : 0u;
-        w2[k] = lo | (hi << 16);
-      }
-    }
-#pragma unroll
-    for (int ri = 0; ri < ((GCV_DW_ABLATE & 1) ? 1 : 6 + RPT); ++ri) {   // input rows oy0 .. oy0 + 6 + RPT - 1
-      const int r = min(oy0 + ri, 12);                 // (clamped rows only feed row slots that are never stored)
-      uint32_t raw[14];
-#pragma unroll
-      for (int s = 0; s < 13; ++s) raw[s] = sIn[(r * 13 + s) * C + c];
-      raw[13] = 0u;
-      uint32_t pp[13];
-#pragma unroll
-      for (int s = 0; s < 13; ++s) pp[s] = raw[s] | (raw[s + 1] << 16);
-#pragma unroll
-      for (int rr = 0; rr < RPT; ++rr) {
-        const int ky = ri - rr;                        // compile-time after unrolling
-        if (ky >= 0 && ky < 7) {
-#pragma unroll
-          for (int ox = 0; ox < 7; ++ox)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[rr][ox] = Dot2<T>::run(pp[ox + 2 * j], w2[ky * 4 + j], acc[rr][ox]);
-        }
-      }
-    }
-  } else {
-    // plain fp32 FMAs (taps exact fp32): at 8 waves per SIMD v_fma_f32 issues every 2 cycles (64 MACs),
-    // which beats v_dot2c_f32_f16 (128 MACs per ~8-10 cycles measured here)
-    float w[49];
-#pragma unroll
-    for (int k = 0; k < 49; ++k) w[k] = wdw[k * C + c];
-#pragma unroll
-    for (int ri = 0; ri < ((GCV_DW_ABLATE & 1) ? 1 : 6 + RPT); ++ri) {
-      const int r = min(oy0 + ri, 12);
-      float v[13];
-#pragma unroll
-      for (int s = 0; s < 13; ++s) v[s] = from_bits16<T>(sIn[(r * 13 + s) * C + c]);
-#pragma unroll
-      for (int rr = 0; rr < RPT; ++rr) {
-        const int ky = ri - rr;
-        if (ky >= 0 && ky < 7) {
-#pragma unroll
-          for (int ox = 0; ox < 7; ++ox)
-#pragma unroll
-            for (int kx = 0; kx < 7; ++kx) acc[rr][ox] = fmaf(v[ox + kx], w[ky * 7 + kx], acc[rr][ox]);
-        }
-      }
-    }
-  }
-  __syncthreads();                                     // halo window is free: reuse it for LayerNorm
-
-#pragma unroll
-  for (int rr = 0; rr < RPT; ++rr) {
-    const int oy = oy0 + rr;
-    if (oy < 7) {
-#pragma unroll
-      for (int ox = 0; ox < 7; ++ox) sval[(oy * 7 + ox) * C + c] = acc[rr][ox];
-    }
-  }
-  __syncthreads();
-  {
-    const int grp = tid >> 5, gl = tid & 31;
-    for (int p = grp; p < ((GCV_DW_ABLATE & 2) ? 0 : 49); p += NT / 32) {
-      const float* row = sval + p * C;
-      float rv[C / 32];                                // the pixel's values stay in registers for both passes
-      float s = 0.0f;
-#pragma unroll
-      for (int k = 0; k < C / 32; ++k) { rv[k] = row[gl + 32 * k]; s += rv[k]; }
-      s = group32_sum(s);
-      const float mean = s * (1.0f / C);
-      float q = 0.0f;
-#pragma unroll
-      for (int k = 0; k < C / 32; ++k) { const float d = rv[k] - mean; q = fmaf(d, d, q); }
-      q = group32_sum(q);
-      if (gl == 0) {
-        stats[2 * p] = mean;
-        stats[2 * p + 1] = 1.0f / sqrtf(q * (1.0f / C) + eps);
-      }
-    }
-  }
-  __syncthreads();
-  {
-    const float lw = lnw[c], lb = lnb[c];
-#pragma unroll
-    for (int rr = 0; rr < RPT; ++rr) {
-      const int oy = oy0 + rr;
-      if (oy < 7) {
-#pragma unroll
-        for (int ox = 0; ox < 7; ++ox) {
-          const int p = oy * 7 + ox;
-          sOut[p * C + c] = (unsigned short)bits16<T>((acc[rr][ox] - stats[2 * p]) * stats[2 * p + 1] * lw + lb);
-        }
-      }
-    }
-  }
-  __syncthreads();
-  for (int idx = tid; idx < 49 * CP; idx += NT) {
-    const int p = idx / CP, pc = idx - p * CP;
-    const int oy = y0 + p / 7, ox = x0 + p % 7;
-    if (oy < H && ox < W && (!(GCV_DW_ABLATE & 16) || sOut[p * C + 8 * pc] == 0x1234)) *(u32x4*)(y + ((img + (int64_t)oy * W + ox) * C + 8 * pc)) = *(const u32x4*)(sOut + p * C + 8 * pc);
   }
 }
 

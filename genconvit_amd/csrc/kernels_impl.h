@@ -39,88 +39,16 @@ static int launch_dw_c(const T* x, const float* wdw, const float* bdw, const flo
   return 0;
 }
 
-template <typename T, int C, int RPT, bool DOT2>
-static int launch_dw_v3(const T* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb, T* y,
-                        int nimg, int H, int W, float eps, hipStream_t s, const uint32_t* wpk) {
-  constexpr int NT = ((7 + RPT - 1) / RPT) * C;
-  constexpr int LDS = 169 * C * 2 + (C == 96 ? 28 * C * 4 : 0);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (LDS > 64 * 1024)
-      GCV_CHECK_HIP(hipFuncSetAttribute((const void*)dwconv7_ln_v3_kernel<T, C, RPT, DOT2>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
-  }
-  const int tiles = nimg * cdiv(H, 7) * cdiv(W, 7);
-  hipLaunchKernelGGL((dwconv7_ln_v3_kernel<T, C, RPT, DOT2>), dim3(tiles), dim3(NT), LDS, s, x, wdw, bdw, lnw, lnb, y, nimg, H,
-                     W, eps, DOT2 ? wpk : nullptr);
-  GCV_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
-template <typename T, int C>
-static int launch_dw_pk(const T* x, const uint32_t* wpk, const float* bdw, const float* lnw, const float* lnb, T* y, int nimg,
-                        int H, int W, float eps, hipStream_t s) {
-  constexpr size_t LDS = (size_t)49 * C * 4 + 49 * 2 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    GCV_CHECK_HIP(hipFuncSetAttribute((const void*)dwconv7_ln_pk_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)LDS));
-    attr_set = true;
-  }
-  const int tiles = nimg * cdiv(H, 7) * cdiv(W, 7);
-  hipLaunchKernelGGL((dwconv7_ln_pk_kernel<T, C>), dim3(tiles), dim3(C), LDS, s, x, wpk, bdw, lnw, lnb, y, nimg, H, W, eps);
-  GCV_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
-// GCV_DWCONV_MODE (A/B switch for profiling): 0 = rolling-strip kernel (default); 8 = the round-1 tile kernels: v3 with
-// packed-pair dot2 taps (16-bit, C <= 192) / packed-tap generic (C >= 384),
-// 1 = v3 with one output row per thread at C = 96, 2 = the generic kernel everywhere, 4 = v3 with fp32 FMA taps
-static inline int dwconv_mode() {
-  static const int mode = [] { const char* e = std::getenv("GCV_DWCONV_MODE"); return e ? std::atoi(e) : 0; }();
-  return mode;
-}
-
-template <typename T> int launch_pack_dw_taps(const float* wdw, uint32_t* out, int C, hipStream_t s) {
-  if constexpr (sizeof(T) == 2) {
-    hipLaunchKernelGGL((pack_dw_taps_kernel<T>), dim3(cdiv(28 * C, 256)), dim3(256), 0, s, wdw, out, C);
-    GCV_CHECK_HIP(hipGetLastError());
-    return 0;
-  }
-  set_error("packed dw taps exist for 16-bit storage only");
-  return -3;
-}
-
 template <typename T>
 int launch_dwconv7_ln(const T* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb, T* y,
-                      int nimg, int H, int W, int C, float eps, hipStream_t s, const uint32_t* wpk) {
+                      int nimg, int H, int W, int C, float eps, hipStream_t s) {
   GCV_REQUIRE(nimg > 0 && H > 0 && W > 0, "dwconv: empty");
-  // default: the rolling-strip kernel (every ConvNeXt-T shape but the 3x3 map of the 112-px pass)
-  if (dwconv_mode() == 0 && dwconv_roll_applicable<T>(H, W, C) &&
+  // the rolling-strip kernel covers every ConvNeXt-T shape but the 3x3 map of the 112-px pass
+  // (GCV_DWCONV_GENERIC=1: A/B switch, the generic tile kernel everywhere)
+  static const bool generic = std::getenv("GCV_DWCONV_GENERIC") != nullptr;
+  if (!generic && dwconv_roll_applicable<T>(H, W, C) &&
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) == 0)
     return launch_dwconv7_ln_roll<T>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, C, eps, s);
-  if constexpr (sizeof(T) == 2) {
-    const int mode = dwconv_mode() == 8 ? 0 : dwconv_mode();
-    if (mode != 2 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0) {
-      if (C == 96) {
-        // two output rows per thread: 384 threads, three workgroups per CU
-        if (mode == 0) return launch_dw_v3<T, 96, 2, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
-        if (mode == 1) return launch_dw_v3<T, 96, 1, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
-        if (mode == 4) return launch_dw_v3<T, 96, 2, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
-      }
-      if (C == 192) {
-        if (mode == 0 || mode == 1) return launch_dw_v3<T, 192, 2, true>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
-        if (mode == 4) return launch_dw_v3<T, 192, 2, false>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s, wpk);
-      }
-    }
-  }
-  if constexpr (sizeof(T) == 2) {
-    if (wpk && dwconv_mode() != 2) {                    // pre-packed taps available: packed-pair variant of the generic kernel
-      if (C == 384) return launch_dw_pk<T, 384>(x, wpk, bdw, lnw, lnb, y, nimg, H, W, eps, s);
-      if (C == 768) return launch_dw_pk<T, 768>(x, wpk, bdw, lnw, lnb, y, nimg, H, W, eps, s);
-    }
-  }
   switch (C) {
     case 96:  return launch_dw_c<T, 96>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
     case 192: return launch_dw_c<T, 192>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
@@ -283,9 +211,8 @@ template <typename T> int launch_preprocess(const unsigned char* u8, T* out, int
 #define GCV_INSTANTIATE_KERNELS(T)                                                                                    \
   template int launch_stem_ln<T>(const T*, int64_t, int64_t, int64_t, int64_t, const float*, const float*,            \
                                  const float*, const float*, T*, int, int, int, float, hipStream_t);                  \
-  template int launch_pack_dw_taps<T>(const float*, uint32_t*, int, hipStream_t);                                    \
   template int launch_dwconv7_ln<T>(const T*, const float*, const float*, const float*, const float*, T*, int, int,   \
-                                    int, int, float, hipStream_t, const uint32_t*);                                   \
+                                    int, int, float, hipStream_t);                                                    \
   template int launch_ln_patchify<T>(const T*, const float*, const float*, T*, int, int, int, int, float, hipStream_t); \
   template int launch_layernorm_rows<T>(const T*, const float*, const float*, T*, int64_t, int, float, hipStream_t);  \
   template int launch_pool_ln<T>(const T*, const float*, const float*, T*, int, int, int, float, hipStream_t);        \

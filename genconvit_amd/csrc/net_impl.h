@@ -94,7 +94,6 @@ template <typename T> struct CnxBlockW {
   float *dw_w, *dw_b, *ln_w, *ln_b, *fc1_b, *fc2_b, *gamma;
   T *fc1_w, *fc2_w;
   T* fc2_wc;       // 16-bit, C <= 384: W2 packed for the fused MLP kernels (else null)
-  uint32_t* dw_wpk; // 16-bit: dw taps as packed pairs [28][C] for the dot2 dw7x7 kernels (fp32 storage: null)
 };
 template <typename T> struct CnxW {
   float *stem_w, *stem_b, *stem_lnw, *stem_lnb;
@@ -312,15 +311,6 @@ template <typename T> struct NetImpl : NetBase {
           for (int c = 0; c < C; ++c)
             for (int q = 0; q < 49; ++q) t[(size_t)q * C + c] = v[(size_t)c * 49 + q];
           GCV_UP(k.dw_w, st, t);
-          k.dw_wpk = nullptr;
-          if constexpr (sizeof(T) == 2) {
-            {
-              k.dw_wpk = (uint32_t*)st.raw((size_t)28 * C * 4);
-              if (!k.dw_wpk) { set_error("hipMalloc failed for packed dw taps"); return -5; }
-              GCV_TRY(launch_pack_dw_taps<T>(k.dw_w, k.dw_wpk, C, nullptr));
-              GCV_CHECK_HIP(hipDeviceSynchronize());
-            }
-          }
         }
         GCV_TRY(up_f32(w, b + "conv_dw.bias", C, st, k.dw_b));
         GCV_TRY(up_f32(w, b + "norm.weight", C, st, k.ln_w));
@@ -540,7 +530,7 @@ template <typename T> struct NetImpl : NetBase {
           while (e < nseg && h[e] == h[s] && wd[e] == wd[s]) { nimg += segs[e].n; mm += m[e]; ++e; }
           GCV_TRY(run("cnx.dwconv7_ln", 2.0 * 49 * mm * C, 2.0 * sizeof(T) * (double)mm * C + 49.0 * C * 4, [&] {
             return launch_dwconv7_ln<T>(X + moff[s] * C, k.dw_w, k.dw_b, k.ln_w, k.ln_b, Y + moff[s] * C, nimg, h[s],
-                                        wd[s], C, 1e-6f, cur, k.dw_wpk);
+                                        wd[s], C, 1e-6f, cur);
           }));
           s = e;
         }
