@@ -203,8 +203,9 @@ class Handle:
         arr, keep, _ = self._descs(state_dict, self._OFF_PATH)
         check(self.lib.gcv_load_ed(self._h, arr, len(keep)), "gcv_load_ed")
 
-    def load_vae(self, state_dict):
-        arr, keep, _ = self._descs(state_dict, self._OFF_PATH)
+    def load_vae(self, state_dict, with_var=True):
+        """``with_var=False`` leaves ``encoder.var`` (1.26 GB fp32, only read for the optional KL output) unpacked."""
+        arr, keep, _ = self._descs(state_dict, self._OFF_PATH + (() if with_var else ("encoder.var.",)))
         check(self.lib.gcv_load_vae(self._h, arr, len(keep)), "gcv_load_vae")
 
     def load_swin(self, state_dict, prefix=""):

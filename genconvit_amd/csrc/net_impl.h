@@ -387,16 +387,27 @@ template <typename T> struct NetImpl : NetBase {
     dst = (T*)ws_vae.raw((size_t)total * sizeof(T));
     if (!dst) { set_error("hipMalloc failed for " + name); return -5; }
     const float* src = it->second.data;
-    float* tmp = nullptr;
-    if (!it->second.on_device) {
-      GCV_CHECK_HIP(hipMalloc((void**)&tmp, (size_t)total * 4));
-      GCV_CHECK_HIP(hipMemcpy(tmp, src, (size_t)total * 4, hipMemcpyHostToDevice));
-      src = tmp;
+    if (it->second.on_device) {
+      hipLaunchKernelGGL((pack_mu_kernel<T>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, 0, src, dst, total);
+      GCV_CHECK_HIP(hipGetLastError());
+      GCV_CHECK_HIP(hipDeviceSynchronize());
+      return 0;
     }
-    hipLaunchKernelGGL((pack_mu_kernel<T>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, 0, src, dst, total);
-    GCV_CHECK_HIP(hipGetLastError());
-    GCV_CHECK_HIP(hipDeviceSynchronize());
-    if (tmp) GCV_CHECK_HIP(hipFree(tmp));
+    // host source (the published 2.6 GB VAE checkpoint, model/genconvit.py:16-21): streamed through a 49 MB staging
+    // buffer, 512 rows at a time (the permutation stays inside a row), so the device never holds an fp32 copy
+    constexpr int64_t kRows = 512;
+    struct DevBuf {
+      float* p = nullptr;
+      ~DevBuf() { if (p) (void)hipFree(p); }
+    } tmp;
+    GCV_CHECK_HIP(hipMalloc((void**)&tmp.p, (size_t)(kRows * 25088 * 4)));
+    for (int64_t r0 = 0; r0 < 12544; r0 += kRows) {
+      const int64_t rows = std::min<int64_t>(kRows, 12544 - r0), n = rows * 25088;
+      GCV_CHECK_HIP(hipMemcpy(tmp.p, src + r0 * 25088, (size_t)n * 4, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL((pack_mu_kernel<T>), dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, 0, tmp.p, dst + r0 * 25088, n);
+      GCV_CHECK_HIP(hipGetLastError());
+      GCV_CHECK_HIP(hipDeviceSynchronize());
+    }
     return 0;
   }
 

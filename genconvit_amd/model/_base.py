@@ -38,6 +38,13 @@ def build_param_tree(root: nn.Module, entries, init: str, seed: int, tag: str):
 OFF_PATH_MARKERS = ("embedder.", "patch_embed.", "num_batches_tracked")
 
 
+# Parameters at least this large (elements) never move to the device as nn.Parameters: the VAE's two 25088 x 12544
+# Linear weights are 1.26 GB each in fp32 and the kernels read the handle's packed copy, not the module's tensors.
+# They stay host-resident (``.to(device)`` / ``.cuda()`` change only their dtype), are packed into the handle
+# tensor by tensor (descriptor ``on_device = 0``), and ``state_dict()`` keeps returning them under the reference's keys.
+HOST_RESIDENT_NUMEL = 1 << 24
+
+
 class HipModule(nn.Module):
     """Base class: parameter tree + handle lifecycle."""
 
@@ -53,7 +60,22 @@ class HipModule(nn.Module):
     # nn.Module._apply is what .to()/.half()/.float()/.cuda() go through
     def _apply(self, fn, *a, **k):
         self._dirty = True
-        return super()._apply(fn, *a, **k)
+        big = [(m, n, p) for m in self.modules() for n, p in m._parameters.items()
+               if p is not None and p.numel() >= HOST_RESIDENT_NUMEL]
+        if not big:
+            return super()._apply(fn, *a, **k)
+        # what does fn do to a floating tensor?  (dtype is kept for the host-resident ones, the device is not)
+        probe = fn(torch.empty(1, dtype=big[0][2].dtype, device=big[0][2].device))
+        for m, n, p in big:
+            del m._parameters[n]
+        try:
+            super()._apply(fn, *a, **k)
+        finally:
+            for m, n, p in big:
+                if p.dtype != probe.dtype and probe.is_floating_point():
+                    p = nn.Parameter(p.detach().to("cpu", probe.dtype), requires_grad=False)
+                m._parameters[n] = p
+        return self
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         own = set(self.state_dict().keys())
@@ -63,7 +85,7 @@ class HipModule(nn.Module):
         return super().load_state_dict(filtered, strict=strict, **kw)
 
     def _param_device_dtype(self):
-        p = next(self.parameters())
+        p = next(q for q in self.parameters() if q.numel() < HOST_RESIDENT_NUMEL)
         return p.device, p.dtype
 
     def _load_into(self, handle):   # subclasses push their weights

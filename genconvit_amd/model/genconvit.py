@@ -18,7 +18,10 @@ from .genconvit_vae import GenConViTVAE
 
 def _read_checkpoint(name):
     path = name if os.path.isabs(name) or name.endswith(".pth") else os.path.join("weight", f"{name}.pth")
-    ckpt = torch.load(path, map_location=torch.device("cpu"))
+    try:       # zip-format checkpoints are memory-mapped: the 2.6 GB VAE file is paged in tensor by tensor
+        ckpt = torch.load(path, map_location=torch.device("cpu"), mmap=True, weights_only=True)
+    except (RuntimeError, ValueError, TypeError):          # legacy (non-zip) files cannot be mapped
+        ckpt = torch.load(path, map_location=torch.device("cpu"))
     return ckpt["state_dict"] if isinstance(ckpt, dict) and "state_dict" in ckpt else ckpt
 
 
@@ -41,6 +44,7 @@ class GenConViT(nn.Module):
                 self.model_vae = GenConViTVAE(config, init="empty")
                 self.model_vae.load_state_dict(_read_checkpoint(vae))
                 self.model_vae.eval()
+                self.model_vae.keep_kl_weights = False     # forward() below drops kl / recon like the reference (:70,73)
         except FileNotFoundError:
             if net == "ed":
                 raise Exception(f"Error: weight/{ed}.pth file not found.")

@@ -27,13 +27,14 @@ class GenConViTVAE(HipModule):
         self.kl = None          # Encoder.kl side effect (genconvit_vae.py:58), filled when want_kl
         self.mse = None
         self._generator = None
+        self.keep_kl_weights = True   # False: encoder.var is not packed (inference never reads it, genconvit.py:70,73)
 
     def set_generator(self, generator):
         """torch.Generator used for eps when none is passed (device generator of the model device)."""
         self._generator = generator
 
     def _load_into(self, handle):
-        handle.load_vae(self.state_dict())
+        handle.load_vae(self.state_dict(), with_var=self.keep_kl_weights)
 
     @torch.no_grad()
     def forward(self, x, eps=None, want_recon=True, want_mse=False, want_kl=False):

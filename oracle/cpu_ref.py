@@ -29,6 +29,35 @@ import torch.nn.functional as F
 from genconvit_amd.spec import (CONVNEXT_DEPTHS, CONVNEXT_DIMS, SWIN_DEPTHS, SWIN_DIMS,
                                 SWIN_HEADS)
 
+# --------------------------------------------------------------------------- same-dtype restatement (16-bit storage)
+# "for 16-bit report the delta vs the fp32 oracle and vs a same-dtype CPU restatement".  Inside
+# ``with storage_dtype(torch.float16 | torch.bfloat16):`` the functions below round (a) the input frames, (b) every
+# weight the HIP path keeps in the storage dtype (the GEMM / conv-as-GEMM weights; biases, LayerNorm affine, layer
+# scale, depthwise taps, the first 3->16 convs, the last 16->3 transposed convs and the 500->2 layer stay fp32, as
+# in genconvit_amd/csrc/net_impl.h) and (c) every activation at the points where the HIP path stores it in HBM or
+# feeds it to a 16-bit MFMA operand — all arithmetic stays fp32, like the kernels' accumulators.  With no storage
+# dtype set (the default) ``_q`` returns its argument untouched: the fp32 oracle is bit-for-bit what it was.
+_STORE = None
+
+
+class storage_dtype:
+    def __init__(self, dtype):
+        self.dtype = None if dtype in (None, torch.float32) else dtype
+
+    def __enter__(self):
+        global _STORE
+        self.prev, _STORE = _STORE, self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        global _STORE
+        _STORE = self.prev
+
+
+def _q(t):
+    return t if _STORE is None else t.to(_STORE).float()
+
+
 LN_EPS_CONVNEXT = 1e-6   # timm ConvNeXt LayerNorm/LayerNorm2d eps
 LN_EPS_SWIN = 1e-5       # timm Swin nn.LayerNorm default
 BN_EPS = 1e-5            # nn.BatchNorm2d default, genconvit_vae.py:16
@@ -39,9 +68,9 @@ LEAKY = 0.01             # nn.LeakyReLU default, genconvit_vae.py:17
 def ed_encoder(sd, x, taps=None):
     """model/genconvit_ed.py:13-36 — 5x[Conv2d 3x3 s1 p1 -> ReLU -> MaxPool 2x2]."""
     for li, idx in enumerate((0, 3, 6, 9, 12)):
-        x = F.conv2d(x, sd[f"encoder.features.{idx}.weight"], sd[f"encoder.features.{idx}.bias"],
-                     stride=1, padding=1)
-        x = F.max_pool2d(F.relu(x), kernel_size=2, stride=2)
+        w = sd[f"encoder.features.{idx}.weight"]
+        x = F.conv2d(x, w if li == 0 else _q(w), sd[f"encoder.features.{idx}.bias"], stride=1, padding=1)
+        x = _q(F.max_pool2d(F.relu(x), kernel_size=2, stride=2))
         if taps is not None:
             taps[f"ed_enc{li}"] = x
     return x
@@ -50,8 +79,8 @@ def ed_encoder(sd, x, taps=None):
 def ed_decoder(sd, x, taps=None):
     """model/genconvit_ed.py:43-61 — 5x[ConvTranspose2d 2x2 s2 -> ReLU]."""
     for li, idx in enumerate((0, 2, 4, 6, 8)):
-        x = F.relu(F.conv_transpose2d(x, sd[f"decoder.features.{idx}.weight"],
-                                      sd[f"decoder.features.{idx}.bias"], stride=2))
+        w = sd[f"decoder.features.{idx}.weight"]
+        x = _q(F.relu(F.conv_transpose2d(x, w if li == 4 else _q(w), sd[f"decoder.features.{idx}.bias"], stride=2)))
         if taps is not None:
             taps[f"ed_dec{li}"] = x
     return x
@@ -69,53 +98,55 @@ def convnext_block(sd, p, x):
     c = x.shape[1]
     y = F.conv2d(x, sd[p + "conv_dw.weight"], sd[p + "conv_dw.bias"], padding=3, groups=c)
     y = y.permute(0, 2, 3, 1)
-    y = F.layer_norm(y, (c,), sd[p + "norm.weight"], sd[p + "norm.bias"], LN_EPS_CONVNEXT)
-    y = F.linear(y, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])
-    y = F.gelu(y)
-    y = F.linear(y, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+    y = _q(F.layer_norm(y, (c,), sd[p + "norm.weight"], sd[p + "norm.bias"], LN_EPS_CONVNEXT))
+    y = F.linear(y, _q(sd[p + "mlp.fc1.weight"]), sd[p + "mlp.fc1.bias"])
+    y = _q(F.gelu(y))
+    y = F.linear(y, _q(sd[p + "mlp.fc2.weight"]), sd[p + "mlp.fc2.bias"])
     y = y.permute(0, 3, 1, 2)
     y = y * sd[p + "gamma"].reshape(1, -1, 1, 1)
-    return y + x
+    return _q(y + x)
 
 
-def convnext_tiny(sd, prefix, x, taps=None):
+def convnext_tiny(sd, prefix, x, taps=None, store_out=True):
     """timm 0.6.5 ``convnext_tiny`` forward: stem -> 4 stages -> (norm_pre=Identity)
     -> head(global avg pool, LayerNorm2d, flatten, fc).  Called by the reference at
     model/genconvit_ed.py:82-83 and model/genconvit_vae.py:111-112."""
     p = prefix
     x = F.conv2d(x, sd[p + "stem.0.weight"], sd[p + "stem.0.bias"], stride=4)
-    x = _ln2d(x, sd[p + "stem.1.weight"], sd[p + "stem.1.bias"], LN_EPS_CONVNEXT)
+    x = _q(_ln2d(x, sd[p + "stem.1.weight"], sd[p + "stem.1.bias"], LN_EPS_CONVNEXT))
     if taps is not None:
         taps["stem"] = x
     for i, depth in enumerate(CONVNEXT_DEPTHS):
         if i > 0:
-            x = _ln2d(x, sd[p + f"stages.{i}.downsample.0.weight"],
-                      sd[p + f"stages.{i}.downsample.0.bias"], LN_EPS_CONVNEXT)
-            x = F.conv2d(x, sd[p + f"stages.{i}.downsample.1.weight"],
-                         sd[p + f"stages.{i}.downsample.1.bias"], stride=2)
+            x = _q(_ln2d(x, sd[p + f"stages.{i}.downsample.0.weight"],
+                         sd[p + f"stages.{i}.downsample.0.bias"], LN_EPS_CONVNEXT))
+            x = _q(F.conv2d(x, _q(sd[p + f"stages.{i}.downsample.1.weight"]),
+                            sd[p + f"stages.{i}.downsample.1.bias"], stride=2))
         for j in range(depth):
             x = convnext_block(sd, p + f"stages.{i}.blocks.{j}.", x)
         if taps is not None:
             taps[f"stage{i}"] = x
     x = x.mean((2, 3), keepdim=True)
-    x = _ln2d(x, sd[p + "head.norm.weight"], sd[p + "head.norm.bias"], LN_EPS_CONVNEXT)
+    x = _q(_ln2d(x, sd[p + "head.norm.weight"], sd[p + "head.norm.bias"], LN_EPS_CONVNEXT))
     x = torch.flatten(x, 1)
-    return F.linear(x, sd[p + "head.fc.weight"], sd[p + "head.fc.bias"])
+    x = F.linear(x, _q(sd[p + "head.fc.weight"]), sd[p + "head.fc.bias"])
+    return _q(x) if store_out else x       # (ED / VAE store it after the head's first activation)
 
 
 # --------------------------------------------------------------------------- ED
 def ed_forward(sd, images, taps=None):
     """GenConViTED.forward, model/genconvit_ed.py:77-88.  cat order is
     [backbone(recon), backbone(orig)]; ``self.relu`` is exact-erf nn.GELU (:75)."""
+    images = _q(images)
     encimg = ed_encoder(sd, images, taps)
     decimg = ed_decoder(sd, encimg, taps)
-    x1 = convnext_tiny(sd, "backbone.", decimg)
-    x2 = convnext_tiny(sd, "backbone.", images, taps)
+    x1 = convnext_tiny(sd, "backbone.", decimg, store_out=False)
+    x2 = convnext_tiny(sd, "backbone.", images, taps, store_out=False)
     x = torch.cat((x1, x2), dim=1)
     if taps is not None:
         taps["ed_feat"] = x
-    x = F.gelu(x)
-    x = F.gelu(F.linear(x, sd["fc.weight"], sd["fc.bias"]))
+    x = _q(F.gelu(x))
+    x = _q(F.gelu(F.linear(x, _q(sd["fc.weight"]), sd["fc.bias"])))
     return F.linear(x, sd["fc2.weight"], sd["fc2.bias"])
 
 
@@ -124,12 +155,18 @@ def vae_encoder_features(sd, x, taps=None):
     """model/genconvit_vae.py:14-31,52-53 — 4x[Conv2d 3x3 s2 p1 -> BatchNorm2d(eval)
     -> LeakyReLU(0.01)] then flatten (C-major)."""
     for li, idx in enumerate((0, 3, 6, 9)):
-        x = F.conv2d(x, sd[f"encoder.features.{idx}.weight"], sd[f"encoder.features.{idx}.bias"],
-                     stride=2, padding=1)
         b = f"encoder.features.{idx + 1}."
-        x = F.batch_norm(x, sd[b + "running_mean"], sd[b + "running_var"], sd[b + "weight"],
-                         sd[b + "bias"], training=False, eps=BN_EPS)
-        x = F.leaky_relu(x, LEAKY)
+        if _STORE is None:
+            x = F.conv2d(x, sd[f"encoder.features.{idx}.weight"], sd[f"encoder.features.{idx}.bias"],
+                         stride=2, padding=1)
+            x = F.batch_norm(x, sd[b + "running_mean"], sd[b + "running_var"], sd[b + "weight"],
+                             sd[b + "bias"], training=False, eps=BN_EPS)
+        else:   # the HIP path folds the eval-mode BatchNorm into the conv, then rounds the folded GEMM weight
+            sc = sd[b + "weight"] / torch.sqrt(sd[b + "running_var"] + BN_EPS)
+            w = sd[f"encoder.features.{idx}.weight"] * sc.view(-1, 1, 1, 1)
+            bias = (sd[f"encoder.features.{idx}.bias"] - sd[b + "running_mean"]) * sc + sd[b + "bias"]
+            x = F.conv2d(x, w if li == 0 else _q(w), bias, stride=2, padding=1)
+        x = _q(F.leaky_relu(x, LEAKY))
         if taps is not None:
             taps[f"vae_enc{li}"] = x
     return torch.flatten(x, start_dim=1)
@@ -143,7 +180,7 @@ def vae_encoder(sd, x, eps, as_written=False, want_kl=False, taps=None):
     ``as_written`` the three redundant ``mu`` GEMMs and the ``var`` GEMM are
     executed like the reference does (CPU-baseline fidelity); results are equal."""
     f = vae_encoder_features(sd, x, taps)
-    mu = F.linear(f, sd["encoder.mu.weight"], sd["encoder.mu.bias"])
+    mu = F.linear(f, _q(sd["encoder.mu.weight"]), sd["encoder.mu.bias"])
     kl = None
     if as_written or want_kl:
         var = F.linear(f, sd["encoder.var.weight"], sd["encoder.var.bias"])
@@ -152,7 +189,7 @@ def vae_encoder(sd, x, eps, as_written=False, want_kl=False, taps=None):
         std = torch.exp(0.5 * F.linear(f, sd["encoder.mu.weight"], sd["encoder.mu.bias"]))
         z = eps * std + F.linear(f, sd["encoder.mu.weight"], sd["encoder.mu.bias"])
     else:
-        z = eps * torch.exp(0.5 * mu) + mu
+        z = _q(eps * torch.exp(0.5 * mu) + mu)
     if taps is not None:
         taps["vae_mu"] = mu
         taps["vae_z"] = z
@@ -164,8 +201,9 @@ def vae_decoder(sd, z, taps=None):
     4x[ConvTranspose2d 2x2 s2 -> LeakyReLU]."""
     x = z.reshape(z.shape[0], 256, 7, 7)
     for li, idx in enumerate((0, 2, 4, 6)):
-        x = F.leaky_relu(F.conv_transpose2d(x, sd[f"decoder.features.{idx}.weight"],
-                                            sd[f"decoder.features.{idx}.bias"], stride=2), LEAKY)
+        w = sd[f"decoder.features.{idx}.weight"]
+        x = _q(F.leaky_relu(F.conv_transpose2d(x, w if li == 3 else _q(w), sd[f"decoder.features.{idx}.bias"],
+                                               stride=2), LEAKY))
         if taps is not None:
             taps[f"vae_dec{li}"] = x
     return x
@@ -182,15 +220,16 @@ def vae_forward(sd, x, eps, as_written=False, want_kl=False, taps=None):
     """GenConViTVAE.forward, model/genconvit_vae.py:107-116.  cat order is
     [backbone(orig @224), backbone(x_hat @112)]; activation is ReLU (:104).
     Returns (logits, resized reconstruction, kl or None)."""
+    x = _q(x)
     z, kl = vae_encoder(sd, x, eps, as_written, want_kl, taps)
     x_hat = vae_decoder(sd, z, taps)
-    x1 = convnext_tiny(sd, "convnext_backbone.", x)
-    x2 = convnext_tiny(sd, "convnext_backbone.", x_hat)
+    x1 = convnext_tiny(sd, "convnext_backbone.", x, store_out=False)
+    x2 = convnext_tiny(sd, "convnext_backbone.", x_hat, store_out=False)
     f = torch.cat((x1, x2), dim=1)
     if taps is not None:
         taps["vae_feat"] = f
-    f = F.relu(f)
-    f = F.relu(F.linear(f, sd["fc.weight"], sd["fc.bias"]))
+    f = _q(F.relu(f))
+    f = _q(F.relu(F.linear(f, _q(sd["fc.weight"]), sd["fc.bias"])))
     logits = F.linear(f, sd["fc2.weight"], sd["fc2.bias"])
     return logits, resize224(x_hat), kl
 

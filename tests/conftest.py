@@ -32,6 +32,13 @@ def golden():
     return dict(np.load(path, allow_pickle=False))
 
 
+@pytest.fixture(scope="session")
+def hf_golden():
+    """Outputs of the independent Hugging Face ConvNeXt / Swin implementations (tests/golden/make_hf_golden.py)."""
+    import numpy as np
+    return dict(np.load(os.path.join(REPO, "tests", "golden", "hf_backbones.npz"), allow_pickle=False))
+
+
 _SD_CACHE = {}
 
 

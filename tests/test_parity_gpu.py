@@ -62,15 +62,30 @@ def test_ed_fp32_matches_reference_golden(golden, sd_ed):
 
 
 @pytest.mark.parametrize("res", [224, 112])
-def test_convnext_fp32_matches_oracle(res, sd_ed):
+def test_convnext_fp32_matches_oracle(res, sd_ed, hf_golden):
+    """ConvNeXt-T alone, against the oracle's restatement AND against the committed outputs of the independent
+    Hugging Face implementation (tests/golden/make_hf_golden.py) — numbers that never went through cpu_ref's backbone."""
     x = synth.make_frames(3, name=f"cnx{res}")
     if res != 224:
         x = torch.nn.functional.avg_pool2d(x, 224 // res)
     got = ed_model().backbone_forward(x.cuda()).cpu()
     want = cpu_ref.convnext_tiny(sd_ed, "backbone.", x)
     err = (got - want).abs().max().item()
-    print(f"\nConvNeXt-T fp32 @{res}: max |logits1000 diff| = {err:.3e} (|want| max {want.abs().max():.2f})")
-    assert err <= FP32_TOL
+    err_hf = np.abs(got.numpy() - hf_golden[f"cnx{res}"]).max()
+    print(f"\nConvNeXt-T fp32 @{res}: max |logits1000 diff| = {err:.3e} vs oracle, {err_hf:.3e} vs Hugging Face "
+          f"(|want| max {want.abs().max():.2f})")
+    assert err <= FP32_TOL and err_hf <= FP32_TOL
+
+
+def test_ed_vae_fp32_match_huggingface_backed_golden(golden, hf_golden):
+    """ED / VAE logits with the backbone evaluated by the independent implementation (the glue around it is the
+    reference's own, pinned bit-exact): the HIP path is within 1e-3 of numbers no line of cpu_ref's ConvNeXt produced."""
+    x = synth.make_frames(4)
+    eps = torch.from_numpy(golden["vae_eps"])
+    e_ed = np.abs(ed_model()(x.cuda()).cpu().numpy() - hf_golden["ed_logits_hf"]).max()
+    e_vae = np.abs(vae_model()(x.cuda(), eps=eps.cuda(), want_recon=False)[0].cpu().numpy() - hf_golden["vae_logits_hf"]).max()
+    print(f"\nfp32 B=4 vs Hugging-Face-backed golden: ed {e_ed:.3e}, vae {e_vae:.3e}")
+    assert e_ed <= FP32_TOL and e_vae <= FP32_TOL
 
 
 def test_vae_fp32_matches_reference_golden(golden, sd_vae):
@@ -192,23 +207,54 @@ def test_missing_weight_key_is_an_error():
 
 
 # ----------------------------------------------------------------------------- 16-bit storage
-@pytest.mark.parametrize("dtype,bound", [(torch.bfloat16, 8e-2), (torch.float16, 2e-2)])
-def test_ed_16bit_delta_vs_fp32_oracle(dtype, bound, golden):
+# Bounds = about 3x what was measured on the MI355X (fp16 6e-4 / 4e-4, bf16 5e-3 / 1e-2 for ed / vae at B=4), against
+# BOTH the fp32 reference golden and the same-dtype CPU restatement (oracle with weights and activations rounded at
+# the HIP path's storage points): a 10x regression cannot pass.
+BOUND_16 = {torch.float16: 2e-3, torch.bfloat16: 3e-2}
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_ed_16bit_delta_vs_fp32_oracle_and_same_dtype_restatement(dtype, golden, sd_ed):
     x = synth.make_frames(4)
     got = ed_model(dtype)(x.cuda()).cpu()
     err = np.abs(got.numpy() - golden["ed_logits"]).max()
-    print(f"\nED {dtype} B=4: |logits - fp32 reference golden| = {err:.3e}")
-    assert err <= bound
+    with cpu_ref.storage_dtype(dtype):
+        same = cpu_ref.ed_forward(sd_ed, x)
+    err_same = (got - same).abs().max().item()
+    pred = np.abs(same.numpy() - golden["ed_logits"]).max()
+    print(f"\nED {dtype} B=4: |logits - fp32 reference golden| = {err:.3e}; vs same-dtype restatement {err_same:.3e} "
+          f"(restatement vs fp32: {pred:.3e})")
+    assert err <= BOUND_16[dtype] and err_same <= BOUND_16[dtype]
 
 
-@pytest.mark.parametrize("dtype,bound", [(torch.bfloat16, 1.5e-1), (torch.float16, 3e-2)])
-def test_vae_16bit_delta_vs_fp32_oracle(dtype, bound, golden):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_vae_16bit_delta_vs_fp32_oracle_and_same_dtype_restatement(dtype, golden, sd_vae):
     x = synth.make_frames(4)
     eps = torch.from_numpy(golden["vae_eps"])
     logits, _ = vae_model(dtype)(x.cuda(), eps=eps.cuda(), want_recon=False)
-    err = np.abs(logits.cpu().numpy() - golden["vae_logits"]).max()
-    print(f"\nVAE {dtype} B=4: |logits - fp32 reference golden| = {err:.3e}")
-    assert err <= bound
+    got = logits.cpu()
+    err = np.abs(got.numpy() - golden["vae_logits"]).max()
+    with cpu_ref.storage_dtype(dtype):
+        same = cpu_ref.vae_forward(sd_vae, x, eps)[0]
+    err_same = (got - same).abs().max().item()
+    print(f"\nVAE {dtype} B=4: |logits - fp32 reference golden| = {err:.3e}; vs same-dtype restatement {err_same:.3e}")
+    assert err <= BOUND_16[dtype] and err_same <= BOUND_16[dtype]
+
+
+def test_full_size_config3_vae_batch32_bf16(sd_vae):
+    """BASELINE.json configs[2]: vae, batch 32, bf16 — at its stated size (M = 125 440 tokens at stage 0 takes the
+    LDS-resident fused MLP and the 128-byte-row DMA ring, which B=4 never reaches): every frame against the fp32
+    oracle and the bf16 restatement, eps fixed."""
+    x = synth.make_frames(32, name="cfg3")
+    eps = synth.make_eps(32, name="cfg3")
+    got = vae_model(torch.bfloat16)(x.cuda(), eps=eps.cuda(), want_recon=False)[0].cpu()
+    want = cpu_ref.vae_forward(sd_vae, x, eps)[0]
+    with cpu_ref.storage_dtype(torch.bfloat16):
+        same = cpu_ref.vae_forward(sd_vae, x, eps)[0]
+    err, err_same = (got - want).abs().max().item(), (got - same).abs().max().item()
+    print(f"\nVAE bf16 B=32: max |logits - fp32 oracle| = {err:.3e}, vs bf16 restatement {err_same:.3e}")
+    assert got.shape == (32, 2) and torch.isfinite(got).all()
+    assert err <= 5e-2 and err_same <= 5e-2
 
 
 # ----------------------------------------------------------------------------- Swin-T embedder (row A6)
@@ -230,12 +276,18 @@ def test_full_size_config4_genconvit_batch128_fp16(golden):
     e_ed = np.abs(big[0:4].numpy() - golden["ed_logits"]).max()
     e_vae = np.abs(big[128:132].numpy() - golden["vae_logits"]).max()
     print(f"\ngenconvit fp16 B=128: rows vs B=4 run: ed {d_ed:.2e} vae {d_vae:.2e}; vs fp32 golden: ed {e_ed:.2e} vae {e_vae:.2e}")
-    assert d_ed <= 1e-2 and d_vae <= 1.5e-2
-    assert e_ed <= 2e-2 and e_vae <= 3e-2
+    assert d_ed <= 2e-3 and d_vae <= 2e-3
+    assert e_ed <= 2e-3 and e_vae <= 2e-3
+    # every one of the 128 frames against the fp32 CPU oracle (about 10 s of host time)
+    from tests.conftest import synthetic_sd
+    want = cpu_ref.genconvit_forward(synthetic_sd("ed"), synthetic_sd("vae"), x, eps.cpu())
+    e_all = (big - want).abs().max().item()
+    print(f"genconvit fp16 B=128: all 256 rows vs fp32 oracle: {e_all:.2e}")
+    assert e_all <= 4e-3
     # shards of 32 reassemble to the same rows (the multi-GPU partition, run back to back on one GPU)
     parts = [g(x[i:i + 32].cuda(), eps=eps[i:i + 32]).float().cpu() for i in range(0, 128, 32)]
     re = torch.cat([torch.cat([p[:32] for p in parts]), torch.cat([p[32:] for p in parts])])
-    assert (re - big).abs().max().item() <= 1.5e-2
+    assert (re - big).abs().max().item() <= 2e-3
 
 
 def swin_model(dtype=torch.float32):
@@ -250,7 +302,7 @@ def swin_model(dtype=torch.float32):
     return _CACHE[key]
 
 
-def test_swin_tiny_fp32_matches_oracle():
+def test_swin_tiny_fp32_matches_oracle(hf_golden):
     """timm swin_tiny_patch4_window7_224 forward (W-MSA/SW-MSA, rel-pos bias, patch merging) vs the
     CPU restatement (itself cross-checked against Hugging Face Swin in tests/test_oracle.py)."""
     from genconvit_amd import spec
@@ -259,8 +311,10 @@ def test_swin_tiny_fp32_matches_oracle():
     got = swin_model()(x.cuda()).cpu()
     want = cpu_ref.swin_tiny(sd, "", x)
     err = (got - want).abs().max().item()
-    print(f"\nSwin-T fp32: max |logits1000 diff| = {err:.3e} (|want| max {want.abs().max():.2f})")
-    assert err <= FP32_TOL
+    err_hf = np.abs(got.numpy() - hf_golden["swin"]).max()
+    print(f"\nSwin-T fp32: max |logits1000 diff| = {err:.3e} vs oracle, {err_hf:.3e} vs Hugging Face "
+          f"(|want| max {want.abs().max():.2f})")
+    assert err <= FP32_TOL and err_hf <= FP32_TOL
 
 
 def test_hybrid_embed_probe_runs_swin_on_the_gpu():
@@ -271,7 +325,7 @@ def test_hybrid_embed_probe_runs_swin_on_the_gpu():
     assert he.grid_size == (1, 1000) and tuple(he.proj.weight.shape) == (768, 1000, 1, 1)
 
 
-@pytest.mark.parametrize("dtype,bound", [(torch.bfloat16, 1.5e-1), (torch.float16, 3e-2)])
+@pytest.mark.parametrize("dtype,bound", [(torch.bfloat16, 9e-2), (torch.float16, 1.2e-2)])   # 3x the measured 3.0e-2 / 3.9e-3
 def test_swin_tiny_16bit_delta(dtype, bound):
     from genconvit_amd import spec
     sd = synth.make_state_dict(spec.swin_tiny_spec(""), synth.DEFAULT_SEED, "swin/")
@@ -315,3 +369,67 @@ def test_pred_vids_batches_videos_and_votes_per_video():
     for gv, d in zip(got, (dfs[0], dfs[2])):
         wv = pred_func.pred_vid(d, g1)
         assert gv[0] == wv[0] and abs(gv[1] - wv[1]) <= 1e-5
+
+
+# ----------------------------------------------------------------------------- rows A14 / N2: load_genconvit from files
+def _published_layout(sd, which):
+    """The key layout of the published checkpoints: the path's tensors plus the Swin
+    embedder registered twice, HybridEmbed.proj and the BatchNorm counters — wrapped as {'state_dict': ...}."""
+    from genconvit_amd import spec
+    out = dict(sd)
+    swin = synth.make_state_dict(spec.swin_tiny_spec(""), synth.DEFAULT_SEED, "swin/")
+    bb = "backbone." if which == "ed" else "convnext_backbone."
+    for k, v in swin.items():
+        out["embedder." + k] = v
+        out[bb + "patch_embed.backbone." + k] = v
+    out[bb + "patch_embed.proj.weight"] = torch.zeros(768, 1000, 1, 1)
+    out[bb + "patch_embed.proj.bias"] = torch.zeros(768)
+    if which == "vae":
+        for i in (1, 4, 7, 10):
+            out[f"encoder.features.{i}.num_batches_tracked"] = torch.tensor(0)
+    return {"epoch": 29, "state_dict": out, "min_loss": 0.1}
+
+
+@pytest.fixture(scope="module")
+def weight_dir(tmp_path_factory):
+    from tests.conftest import synthetic_sd
+    d = tmp_path_factory.mktemp("gcv_weights")
+    (d / "weight").mkdir()
+    torch.save(_published_layout(synthetic_sd("ed"), "ed"), d / "weight" / "genconvit_ed_inference.pth")
+    torch.save(_published_layout(synthetic_sd("vae"), "vae"), d / "weight" / "genconvit_vae_inference.pth")
+    return d
+
+
+@pytest.mark.parametrize("fp16", [False, True])
+def test_load_genconvit_and_pred_vid_from_published_layout_files(weight_dir, monkeypatch, golden, fp16):
+    """model/pred_func.py:18-64 + :111-120 end to end on the GPU: load_genconvit(config, net, ed, vae, fp16) reads
+    weight/{name}.pth (full-size files in the published layout, both Swin copies and the {'state_dict': ...}
+    wrapper included), pred_vid votes.  Also row N2: what the load leaves on the device."""
+    from tests.conftest import synthetic_sd
+    monkeypatch.chdir(weight_dir)                                  # weight/ is resolved against the cwd (genconvit.py:16)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    model = pred_func.load_genconvit(load_config(), "genconvit", "genconvit_ed_inference", "genconvit_vae_inference", fp16)
+    assert next(model.parameters()).is_cuda                       # pred_vid's device discovery (:114)
+    assert model.model_vae.encoder.mu.weight.device.type == "cpu"  # the 1.26 GB matrices stay host-resident
+    x = synth.make_frames(4)
+    seed = 1234
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    model.model_vae.set_generator(g)
+    y, val = pred_func.pred_vid(x, model)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()                                       # (count what is held, not the allocator's free blocks)
+    used = (free0 - torch.cuda.mem_get_info()[0]) / 2**30
+    g2 = torch.Generator(device="cuda"); g2.manual_seed(seed)
+    eps = torch.randn((4, 12544), dtype=torch.float32, device="cuda", generator=g2).cpu()
+    want = cpu_ref.genconvit_forward(synthetic_sd("ed"), synthetic_sd("vae"), x, eps)
+    wy, wval = cpu_ref.vote(want)
+    print(f"\nload_genconvit(fp16={fp16}) + pred_vid: ({y}, {val:.5f}) vs oracle ({wy}, {wval:.5f}); device memory in use "
+          f"after load + one forward: {used:.2f} GiB (packed weights + two B<=32 workspaces; the fp32 nn.Parameters alone "
+          f"would be 2.8 GiB, round 1 held them plus 2.4-2.6 GiB of packed copies)")
+    assert y == wy and abs(val - wval) <= (2e-3 if fp16 else 1e-4)
+    assert used < (2.0 if fp16 else 3.0)
+    sd = model.state_dict()
+    assert "model_vae.encoder.mu.weight" in sd and sd["model_vae.encoder.mu.weight"].shape == (12544, 25088)
+    with pytest.raises(_lib.GenConViTHipError, match="encoder.var"):
+        model.model_vae(x.cuda(), want_kl=True)                   # inference wrapper leaves encoder.var unpacked
