@@ -51,6 +51,11 @@ SIGNATURES = {
     "gcv_load_swin": (c_int, [c_void_p, ctypes.POINTER(TensorDesc), c_int, c_char_p]),
     "gcv_ed_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "gcv_vae_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gcv_genconvit_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "gcv_comm_unique_id": (c_int, [c_void_p]),
+    "gcv_comm_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_void_p, c_int]),
+    "gcv_comm_destroy": (None, [c_void_p]),
+    "gcv_allgather_logits": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "gcv_convnext_forward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "gcv_swin_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "gcv_vote": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
@@ -237,8 +242,8 @@ class Handle:
         import torch
         x = self._check_x(x)
         B = x.shape[0]
-        if not (torch.is_tensor(eps) and eps.is_cuda and tuple(eps.shape) == (B, 12544)):
-            raise GenConViTHipError(f"eps must be a device tensor of shape ({B},12544)")
+        if not (torch.is_tensor(eps) and eps.is_cuda and eps.device.index == self.device_index and tuple(eps.shape) == (B, 12544)):
+            raise GenConViTHipError(f"eps must be a tensor of shape ({B},12544) on device {self.device_index}")
         eps = eps.float().contiguous()
         out = torch.empty((B, 2), dtype=torch.float32, device=x.device)
         recon = torch.empty((B, 3, 224, 224), dtype=self.dtype, device=x.device) if want_recon else None
@@ -273,6 +278,65 @@ class Handle:
 
     def profile_report(self):
         return json.loads((self.lib.gcv_profile_report(self._h) or b"[]").decode())
+
+
+def genconvit_forward(h_ed: "Handle", h_vae: "Handle", x, eps):
+    """``GenConViT.forward`` for net='genconvit' (model/genconvit.py:66-75) through ``gcv_genconvit_forward``: ED and VAE
+    on two streams inside the library, joined back into the current stream; returns the (2B,2) fp32 logits."""
+    import torch
+    x = h_ed._check_x(x)
+    B = x.shape[0]
+    if h_vae.device_index != h_ed.device_index or h_vae.dtype != h_ed.dtype:
+        raise GenConViTHipError("ED and VAE handles must share device and dtype")
+    if not (torch.is_tensor(eps) and eps.is_cuda and eps.device.index == h_ed.device_index and tuple(eps.shape) == (B, 12544)):
+        raise GenConViTHipError(f"eps must be a tensor of shape ({B},12544) on device {h_ed.device_index}")
+    eps = eps.float().contiguous()
+    out = torch.empty((2 * B, 2), dtype=torch.float32, device=x.device)
+    check(h_ed.lib.gcv_genconvit_forward(h_ed._h, h_vae._h, x.data_ptr(), eps.data_ptr(), B, out.data_ptr(),
+                                         current_stream_ptr(x.device)), "gcv_genconvit_forward")
+    return out
+
+
+class Comm:
+    """RCCL communicator of the C ABI (``gcv_comm_*``): one per process group, used for the logit all-gather."""
+
+    def __init__(self, world: int, rank: int, unique_id: bytes, device_index: int):
+        self.lib = load()
+        self.world, self.rank, self.device_index = int(world), int(rank), int(device_index)
+        self._c = c_void_p()
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        check(self.lib.gcv_comm_create(ctypes.byref(self._c), self.world, self.rank, buf, self.device_index), "gcv_comm_create")
+
+    @staticmethod
+    def unique_id() -> bytes:
+        try:                  # share torch's RCCL the way the HIP runtime is shared
+            import torch
+            os.environ.setdefault("GCV_RCCL_PATH", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+        except Exception:
+            pass
+        buf = ctypes.create_string_buffer(128)
+        check(load().gcv_comm_unique_id(buf), "gcv_comm_unique_id")
+        return buf.raw
+
+    def allgather(self, local):
+        """local: fp32 device tensor (same numel on every rank) -> (world, *local.shape)."""
+        import torch
+        local = local.float().contiguous()
+        out = torch.empty((self.world,) + tuple(local.shape), dtype=torch.float32, device=local.device)
+        check(self.lib.gcv_allgather_logits(self._c, local.data_ptr(), local.numel(), out.data_ptr(),
+                                            current_stream_ptr(local.device)), "gcv_allgather_logits")
+        return out
+
+    def close(self):
+        if getattr(self, "_c", None) is not None and self._c:
+            self.lib.gcv_comm_destroy(self._c)
+            self._c = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def preprocess(frames_u8, dtype=None):

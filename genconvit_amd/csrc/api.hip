@@ -1,9 +1,15 @@
 // C ABI of libgenconvit_hip.so — see include/genconvit_hip.h for the contract.
 #include "../../include/genconvit_hip.h"
 
+#include <dlfcn.h>
+
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <map>
+#include <mutex>
 #include <sstream>
+#include <vector>
 
 #include "fused_mlp.h"
 #include "gemm.h"
@@ -33,7 +39,60 @@ using namespace gcv;
 struct gcv_handle {
   NetBase* net;
   std::string report;
+  // gcv_genconvit_forward: side streams + fork / join events, created on first use (kept on the ED handle)
+  hipStream_t side[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
 };
+
+// ---- RCCL, bound at run time ----------------------------------------------------------------------------------
+namespace {
+struct NcclId { char b[128]; };   // ncclUniqueId (rccl.h: char internal[NCCL_UNIQUE_ID_BYTES = 128]), passed by value
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string err;
+};
+Rccl& rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    std::vector<std::pair<std::string, int>> cands;
+    if (const char* e = std::getenv("GCV_RCCL_PATH")) cands.push_back({e, RTLD_NOW | RTLD_GLOBAL});
+    for (const char* n : {"librccl.so", "librccl.so.1"}) cands.push_back({n, RTLD_NOW | RTLD_NOLOAD});   // already in the process
+    for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) cands.push_back({n, RTLD_NOW | RTLD_GLOBAL});
+    for (auto& c : cands) {
+      r.lib = dlopen(c.first.c_str(), c.second);
+      if (r.lib) break;
+    }
+    if (!r.lib) { r.err = "cannot load RCCL (librccl.so): set GCV_RCCL_PATH"; return; }
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+    r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) r.err = "librccl.so lacks the nccl* entry points";
+  });
+  return r;
+}
+}  // namespace
+
+struct gcv_comm {
+  void* comm = nullptr;   // ncclComm_t
+  int world = 1, rank = 0, device = 0;
+};
+#define GCV_CHECK_NCCL(expr)                                                                          \
+  do {                                                                                                \
+    int _e = (expr);                                                                                  \
+    if (_e != 0) {                                                                                    \
+      Rccl& _r = rccl();                                                                              \
+      set_error(std::string(#expr) + ": " + (_r.GetErrorString ? _r.GetErrorString(_e) : "RCCL error")); \
+      return -7;                                                                                      \
+    }                                                                                                 \
+  } while (0)
 
 static int to_map(const gcv_tensor_desc* w, int n, TensorMap& m) {
   GCV_REQUIRE(w != nullptr && n > 0, "empty tensor list");
@@ -77,6 +136,11 @@ int gcv_create(gcv_handle** out, int device, int dtype, int max_batch) {
 
 void gcv_destroy(gcv_handle* h) {
   if (!h) return;
+  for (int i = 0; i < 2; ++i) {
+    if (h->side[i]) (void)hipStreamDestroy(h->side[i]);
+    if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+  }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   delete h->net;
   delete h;
 }
@@ -102,29 +166,100 @@ int gcv_load_swin(gcv_handle* h, const gcv_tensor_desc* w, int n, const char* pr
   return h->net->load_swin(m, prefix ? prefix : "");
 }
 
+// the forwards make the handle's device current for their launches and restore the caller's afterwards
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev); else prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 int gcv_ed_forward(gcv_handle* h, const void* x_nchw, int batch, float* logits, gcv_stream stream) {
   GCV_REQUIRE(h, "null handle");
-  GCV_CHECK_HIP(hipSetDevice(h->net->device));
+  DeviceGuard g(h->net->device);
   return h->net->ed_forward(x_nchw, batch, logits, (hipStream_t)stream);
+}
+
+int gcv_genconvit_forward(gcv_handle* he, gcv_handle* hv, const void* x_nchw, const float* eps, int batch,
+                          float* logits, gcv_stream stream) {
+  GCV_REQUIRE(he && hv && he != hv, "two distinct handles (ED, VAE) are needed");
+  GCV_REQUIRE(he->net->device == hv->net->device && he->net->dtype == hv->net->dtype, "ED and VAE handles differ in device / dtype");
+  GCV_REQUIRE(x_nchw && eps && logits && batch >= 1, "null input / eps / output");
+  DeviceGuard g(he->net->device);
+  if (!he->side[0]) {
+    for (int i = 0; i < 2; ++i) {
+      GCV_CHECK_HIP(hipStreamCreateWithFlags(&he->side[i], hipStreamNonBlocking));
+      GCV_CHECK_HIP(hipEventCreateWithFlags(&he->ev_join[i], hipEventDisableTiming));
+    }
+    GCV_CHECK_HIP(hipEventCreateWithFlags(&he->ev_fork, hipEventDisableTiming));
+  }
+  hipStream_t s = (hipStream_t)stream;
+  GCV_CHECK_HIP(hipEventRecord(he->ev_fork, s));
+  GCV_CHECK_HIP(hipStreamWaitEvent(he->side[0], he->ev_fork, 0));
+  GCV_CHECK_HIP(hipStreamWaitEvent(he->side[1], he->ev_fork, 0));
+  int rc = he->net->ed_forward(x_nchw, batch, logits, he->side[0]);
+  if (!rc) rc = hv->net->vae_forward(x_nchw, eps, batch, logits + (size_t)batch * 2, nullptr, nullptr, nullptr, he->side[1]);
+  // join even after an error: whatever was enqueued must be ordered before the caller's next work on `stream`
+  for (int i = 0; i < 2; ++i) {
+    if (hipEventRecord(he->ev_join[i], he->side[i]) == hipSuccess) (void)hipStreamWaitEvent(s, he->ev_join[i], 0);
+  }
+  return rc;
+}
+
+int gcv_comm_unique_id(void* id128) {
+  GCV_REQUIRE(id128, "null id buffer");
+  Rccl& r = rccl();
+  GCV_REQUIRE(r.err.empty(), r.err);
+  GCV_CHECK_NCCL(r.GetUniqueId(id128));
+  return 0;
+}
+
+int gcv_comm_create(gcv_comm** out, int world, int rank, const void* id128, int device) {
+  GCV_REQUIRE(out && id128 && world >= 1 && rank >= 0 && rank < world, "comm: bad arguments");
+  *out = nullptr;
+  Rccl& r = rccl();
+  GCV_REQUIRE(r.err.empty(), r.err);
+  DeviceGuard g(device);
+  NcclId id;
+  std::memcpy(id.b, id128, 128);
+  void* comm = nullptr;
+  GCV_CHECK_NCCL(r.CommInitRank(&comm, world, id, rank));
+  *out = new gcv_comm{comm, world, rank, device};
+  return 0;
+}
+
+void gcv_comm_destroy(gcv_comm* c) {
+  if (!c) return;
+  if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);
+  delete c;
+}
+
+int gcv_allgather_logits(gcv_comm* c, const float* local, int n_local, float* all, gcv_stream stream) {
+  GCV_REQUIRE(c && local && all && n_local > 0, "allgather: bad arguments");
+  DeviceGuard g(c->device);
+  GCV_CHECK_NCCL(rccl().AllGather(local, all, (size_t)n_local, /* ncclFloat32 */ 7, c->comm, (hipStream_t)stream));
+  return 0;
 }
 
 int gcv_vae_forward(gcv_handle* h, const void* x_nchw, const float* eps, int batch, float* logits, void* recon224,
                     float* mse, float* kl, gcv_stream stream) {
   GCV_REQUIRE(h, "null handle");
-  GCV_CHECK_HIP(hipSetDevice(h->net->device));
+  DeviceGuard g(h->net->device);
   return h->net->vae_forward(x_nchw, eps, batch, logits, recon224, mse, kl, (hipStream_t)stream);
 }
 
 int gcv_convnext_forward(gcv_handle* h, int which, const void* x_nchw, int batch, int res, void* logits1000,
                          gcv_stream stream) {
   GCV_REQUIRE(h, "null handle");
-  GCV_CHECK_HIP(hipSetDevice(h->net->device));
+  DeviceGuard g(h->net->device);
   return h->net->convnext_forward(which, x_nchw, batch, res, logits1000, (hipStream_t)stream);
 }
 
 int gcv_swin_forward(gcv_handle* h, const void* x_nchw, int batch, void* logits1000, gcv_stream stream) {
   GCV_REQUIRE(h, "null handle");
-  GCV_CHECK_HIP(hipSetDevice(h->net->device));
+  DeviceGuard g(h->net->device);
   return h->net->swin_forward(x_nchw, batch, logits1000, (hipStream_t)stream);
 }
 

@@ -9,8 +9,34 @@ latency-bound).  Rows are then re-ordered to the reference's ``cat((ed, vae), di
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
+
+_COMMS = {}       # process group -> genconvit_amd._lib.Comm (RCCL through the C ABI)
+
+
+def _c_comm(group, device):
+    """The C-ABI RCCL communicator of ``group`` (created on first use: rank 0's ncclUniqueId travels over the
+    torch.distributed group).  None when the group is not an RCCL ("nccl") group of device tensors, or when
+    GCV_DIST_TORCH=1 asks for torch.distributed's own all_gather."""
+    if device.type != "cuda" or os.environ.get("GCV_DIST_TORCH") == "1" or dist.get_backend(group) != "nccl":
+        return None
+    key = id(group) if group is not None else 0
+    if key not in _COMMS:
+        from . import _lib
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        uid = [_lib.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        _COMMS[key] = _lib.Comm(world, rank, uid[0], device.index if device.index is not None else torch.cuda.current_device())
+    return _COMMS[key]
+
+
+def close_comms():
+    for c in _COMMS.values():
+        c.close()
+    _COMMS.clear()
 
 
 def shard_bounds(n_frames: int, world_size: int, rank: int):
@@ -34,8 +60,12 @@ def gather_logits(local_logits: torch.Tensor, n_frames: int, nets: int, group=No
     slab = torch.zeros((nets, bmax, 2), dtype=torch.float32, device=local_logits.device)
     if bl:
         slab[:, :bl] = local_logits.float().reshape(nets, bl, 2)
-    out = [torch.empty_like(slab) for _ in range(world)]
-    dist.all_gather(out, slab, group=group)
+    comm = _c_comm(group, slab.device)
+    if comm is not None:                      # gcv_allgather_logits: RCCL through the C ABI, on the current stream
+        out = comm.allgather(slab)
+    else:                                     # gloo (CPU tests) or GCV_DIST_TORCH=1
+        out = [torch.empty_like(slab) for _ in range(world)]
+        dist.all_gather(out, slab, group=group)
     full = torch.empty((nets, n_frames, 2), dtype=torch.float32, device=local_logits.device)
     for r, (rlo, rhi) in enumerate(sizes):
         if rhi > rlo:

@@ -12,6 +12,7 @@ import os
 import torch
 import torch.nn as nn
 
+from .. import _lib
 from .genconvit_ed import GenConViTED
 from .genconvit_vae import GenConViTVAE
 
@@ -27,7 +28,6 @@ def _read_checkpoint(name):
 
 class GenConViT(nn.Module):
     concurrent = True        # run ED and VAE on two streams when net is the ensemble (class-level switch)
-    _streams = None
 
     def __init__(self, config, ed, vae, net, fp16):
         super().__init__()
@@ -74,29 +74,20 @@ class GenConViT(nn.Module):
             return self.model_ed(x)
         if self.net == "vae":
             return self.model_vae(x, eps=eps, want_recon=False)[0]
-        if x.is_cuda and self.concurrent:
-            # ED and VAE are independent until the concat: each network has its own handle / workspace, so
-            # they run on two HIP streams and the GPU overlaps one network's small-grid kernels (14x14 and
-            # 7x7 stages, heads) with the other's instead of draining between launches
-            cur = torch.cuda.current_stream(x.device)
-            if self._streams is None or self._streams[0].device != x.device:
-                self._streams = (torch.cuda.Stream(x.device), torch.cuda.Stream(x.device))
-            s_ed, s_vae = self._streams
-            s_ed.wait_stream(cur)
-            s_vae.wait_stream(cur)
-            with torch.cuda.stream(s_ed):
-                x1 = self.model_ed(x)
-            with torch.cuda.stream(s_vae):
-                x2 = self.model_vae(x, eps=eps, want_recon=False)[0]
-            cur.wait_stream(s_ed)
-            cur.wait_stream(s_vae)
-            x.record_stream(s_ed)
-            x.record_stream(s_vae)
-            if eps is not None:
-                eps.record_stream(s_vae)
-            x1.record_stream(cur)
-            x2.record_stream(cur)
-            return torch.cat((x1, x2), dim=0)
+        if self.concurrent and next(self.model_ed.parameters()).is_cuda:
+            # ED and VAE are independent until the concat: gcv_genconvit_forward runs them on two streams inside the
+            # library (each network has its own handle / workspace) and joins them back into the current stream, so
+            # the GPU overlaps one network's small-grid kernels (14x14 and 7x7 stages, heads) with the other's
+            x = self.model_ed._prep_input(x)
+            B = x.shape[0]
+            if B == 0:
+                return torch.empty((0, 2), dtype=torch.float32, device=x.device)
+            if eps is None:
+                eps = torch.randn((B, self.model_vae.latent_dims), dtype=torch.float32, device=x.device,
+                                  generator=self.model_vae._generator)
+            else:
+                eps = eps.to(device=x.device, dtype=torch.float32)
+            return _lib.genconvit_forward(self.model_ed._get_handle(B), self.model_vae._get_handle(B), x, eps)
         x1 = self.model_ed(x)
         x2 = self.model_vae(x, eps=eps, want_recon=False)[0]
         return torch.cat((x1, x2), dim=0)

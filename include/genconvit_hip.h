@@ -75,6 +75,15 @@ int gcv_ed_forward(gcv_handle* h, const void* x_nchw, int batch, float* logits, 
 int gcv_vae_forward(gcv_handle* h, const void* x_nchw, const float* eps, int batch, float* logits,
                     void* recon224, float* mse, float* kl, gcv_stream stream);
 
+/* GenConViT.forward for net = 'genconvit' (model/genconvit.py:66-75): logits_2Bx2 = cat((ed(x), vae(x)[0]), dim=0),
+ * rows 0..B-1 = ED logits of frames 0..B-1, rows B..2B-1 = VAE logits.  The two networks are independent until the
+ * concat: they run on two internal streams forked from `stream` and joined back into it with events, so a C caller
+ * gets the overlapped step (one network's small-grid kernels fill the other's tails) without managing streams.
+ * `h_ed` / `h_vae`: two handles of one device and dtype with gcv_load_ed / gcv_load_vae done (each owns its own
+ * workspace).  eps as in gcv_vae_forward. */
+int gcv_genconvit_forward(gcv_handle* h_ed, gcv_handle* h_vae, const void* x_nchw, const float* eps, int batch,
+                          float* logits_2Bx2, gcv_stream stream);
+
 /* timm convnext_tiny forward alone (call sites model/genconvit_ed.py:82-83,
  * model/genconvit_vae.py:111-112): which = 0 the ED backbone, 1 the VAE backbone;
  * x (B,3,res,res) -> logits1000 (B,1000) in the handle dtype. */
@@ -97,6 +106,20 @@ int gcv_vote(const float* logits, int rows, float* mean2, gcv_stream stream);
  * mean2[v][c] = mean over its frames and nets of sigmoid(logit[.][c]) — what max_prediction_value reduces per video. */
 int gcv_vote_segments(const float* logits, int batch, int nets, const int* offsets, int n_videos, float* mean2,
                       gcv_stream stream);
+
+/* ---- multi-GPU: frame shards, one process per GPU, RCCL over xGMI (new capability: the reference is single
+ * device, model/pred_func.py:15).  The only exchange of the path is one all-gather of per-frame logits before the
+ * vote.  RCCL is bound at run time (dlopen: $GCV_RCCL_PATH, an already loaded librccl, then
+ * /opt/rocm/lib) so that the library shares the process's RCCL the way it shares its HIP runtime.
+ *   gcv_comm_unique_id : rank 0 fills 128 bytes (ncclUniqueId); the caller ships them to every rank (any channel)
+ *   gcv_comm_create    : collective over all `world` ranks (ncclCommInitRank) on `device`
+ *   gcv_allgather_logits: all[r * n_local .. (r+1) * n_local) = rank r's `local` (n_local floats, equal on all
+ *                        ranks: pad ragged shards), enqueued on `stream`; world = 1 is a device copy */
+typedef struct gcv_comm gcv_comm;
+int  gcv_comm_unique_id(void* id128);
+int  gcv_comm_create(gcv_comm** c, int world, int rank, const void* id128, int device);
+void gcv_comm_destroy(gcv_comm* c);
+int  gcv_allgather_logits(gcv_comm* c, const float* local, int n_local, float* all, gcv_stream stream);
 
 /* Per-launch timing with HIP events on the launch stream.  After gcv_profile_enable(h,1) every
  * kernel launch of the following forwards is bracketed by events; gcv_profile_report() waits for

@@ -2,13 +2,18 @@
 # HBM traffic of the bench step per kernel family, from rocprofv3 PMC counters (separate passes for FETCH_SIZE and
 # WRITE_SIZE: they do not fit one TCC pass; no trace domains mixed in).  Writes <out>/traffic.json.
 # gfx950: FETCH_SIZE (KB) reads 1/2 of a wide coalesced stream -> doubled (MI355X_MICROARCH.md §HBM); WRITE_SIZE is exact.
-out=$1; R=${GRAFT_REPO_ROOT:-$PWD}; mkdir -p $R/$out
+# usage: pmc_bench_traffic.sh <outdir> [bench.py args, e.g. --net vae --batch 32 --dtype bf16]
+out=$1; shift; ARGS="$@"; R=${GRAFT_REPO_ROOT:-$PWD}; mkdir -p $R/$out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$out/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 > $R/$out/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$out/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 > $R/$out/write.log 2>&1
-python3 - "$R/$out" <<'PY'
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$out/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 $ARGS > $R/$out/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$out/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 $ARGS > $R/$out/write.log 2>&1
+python3 - "$R/$out" $ARGS <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]
+import argparse
+ap = argparse.ArgumentParser(); ap.add_argument("--net", default="genconvit"); ap.add_argument("--batch", type=int, default=128)
+ap.add_argument("--dtype", default="f16")
+cfg, _ = ap.parse_known_args(sys.argv[2:])
 def load(sub, name):
     d = collections.defaultdict(lambda: [0, 0.0])
     for f in glob.glob(f"{out}/{sub}/*/*counter_collection.csv"):
@@ -28,7 +33,8 @@ for k in set(fe) | set(wr):
 for f in res.values():
     n = max(f["dispatches"], 1)
     f["hbm_bytes_per_launch"] = (f["read_bytes"] + f["write_bytes"]) / n
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `bench.py --steps 2 --warmup 1 --profile-steps 1` "
+if not res: sys.exit("no *counter_collection.csv found under " + out)
+json.dump({"config": {"net": cfg.net, "batch": cfg.batch, "dtype": cfg.dtype}, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `bench.py --steps 2 --warmup 1 --profile-steps 1` "
                    "(4 forward steps), FETCH_SIZE x2 per the gfx950 correction", "families": res}, open(out + "/traffic.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: pmc_mem.sh <outdir> <microbench target> — HBM/L2 traffic counters in separate passes (TCC: FETCH_SIZE costs 3
 # slots, WRITE_SIZE 2).  gfx950: FETCH_SIZE reads 1/2 of a wide coalesced stream (MI355X_MICROARCH.md §HBM) — doubled below.
-out=$1; tgt=$2; R=${GRAFT_REPO_ROOT:-$PWD}
+out=$1; tgt=$2; R=${GRAFT_REPO_ROOT:-$PWD}; mkdir -p $R/$out
 cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
@@ -17,6 +17,7 @@ for f in glob.glob(out + "/mem*/*/*counter_collection.csv"):
         k = r["Kernel_Name"]
         if "gcv" not in k: continue
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[(k, r["Counter_Name"])] += 1
+if not agg: sys.exit("no *counter_collection.csv with gcv kernels found under " + out)
 for k, d in agg.items():
     print("==", k[:110])
     for c, v in sorted(d.items()):

@@ -433,3 +433,59 @@ def test_load_genconvit_and_pred_vid_from_published_layout_files(weight_dir, mon
     assert "model_vae.encoder.mu.weight" in sd and sd["model_vae.encoder.mu.weight"].shape == (12544, 25088)
     with pytest.raises(_lib.GenConViTHipError, match="encoder.var"):
         model.model_vae(x.cuda(), want_kl=True)                   # inference wrapper leaves encoder.var unpacked
+
+
+# ----------------------------------------------------------------------------- C boundary: ensemble entry point, RCCL
+def test_genconvit_forward_entry_point_equals_the_two_separate_forwards(golden):
+    """gcv_genconvit_forward (model/genconvit.py:66-75 behind one C call: ED and VAE on two internal streams, joined with
+    events) returns exactly what gcv_ed_forward + gcv_vae_forward + cat return."""
+    x = synth.make_frames(6, name="ens").cuda()
+    eps = synth.make_eps(6, name="ens").cuda()
+    g = GenConViT.from_modules(ed_model(), vae_model(), net="genconvit")
+    try:
+        GenConViT.concurrent = True
+        a = g(x, eps=eps)
+        b = g(x, eps=eps)
+        GenConViT.concurrent = False
+        c = g(x, eps=eps)
+    finally:
+        GenConViT.concurrent = True
+    torch.cuda.synchronize()
+    assert a.shape == (12, 2) and torch.equal(a, b) and torch.equal(a, c)
+    # a second current stream: the fork / join must order against whatever stream the caller is on
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        d = g(x, eps=eps)
+    s.synchronize()
+    assert torch.equal(a, d)
+
+
+def test_rccl_allgather_through_the_c_abi_world_size_1():
+    """gcv_comm_create / gcv_allgather_logits on RCCL with a single rank (the 1-GPU box), directly and through
+    genconvit_amd.dist.gather_logits on an "nccl" process group; no 1 -> 8 curve has been measured on hardware."""
+    import torch.distributed as tdist
+    from genconvit_amd import dist as gdist
+    uid = _lib.Comm.unique_id()
+    assert len(uid) == 128
+    c = _lib.Comm(1, 0, uid, 0)
+    t = torch.arange(24, dtype=torch.float32, device="cuda").reshape(2, 6, 2)
+    out = c.allgather(t)
+    torch.cuda.synchronize()
+    assert out.shape == (1, 2, 6, 2) and torch.equal(out[0], t)
+    c.close()
+    if not tdist.is_initialized():
+        import os
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        own = True
+    else:
+        own = False
+    try:
+        local = torch.randn(10, 2, device="cuda")           # nets = 2, 5 frames
+        full = gdist.gather_logits(local, 5, 2)
+        assert torch.equal(full, local) and len(gdist._COMMS) == 1
+    finally:
+        gdist.close_comms()
+        if own:
+            tdist.destroy_process_group()
