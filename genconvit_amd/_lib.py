@@ -204,16 +204,25 @@ class Handle:
 
     _OFF_PATH = ("embedder.", "patch_embed.", "encoder.fc1.", "encoder.fc2.", "fc3.", "num_batches_tracked")
 
+    def _settle(self):
+        """The library reads the tensors with synchronous copies / null-stream kernels: whatever stream produced them
+        (a non-blocking ``.to()``, a cast on a side stream) must have finished first."""
+        import torch
+        torch.cuda.synchronize(self.device_index)
+
     def load_ed(self, state_dict):
+        self._settle()
         arr, keep, _ = self._descs(state_dict, self._OFF_PATH)
         check(self.lib.gcv_load_ed(self._h, arr, len(keep)), "gcv_load_ed")
 
     def load_vae(self, state_dict, with_var=True):
         """``with_var=False`` leaves ``encoder.var`` (1.26 GB fp32, only read for the optional KL output) unpacked."""
+        self._settle()
         arr, keep, _ = self._descs(state_dict, self._OFF_PATH + (() if with_var else ("encoder.var.",)))
         check(self.lib.gcv_load_vae(self._h, arr, len(keep)), "gcv_load_vae")
 
     def load_swin(self, state_dict, prefix=""):
+        self._settle()
         arr, keep, _ = self._descs(state_dict)
         check(self.lib.gcv_load_swin(self._h, arr, len(keep), prefix.encode()), "gcv_load_swin")
 

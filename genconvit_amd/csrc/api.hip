@@ -21,6 +21,19 @@ static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
 const char* get_error() { return g_err.c_str(); }
 
+int ensure_dynamic_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> done;     // (function, device) -> bytes granted
+  int dev = 0;
+  GCV_CHECK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = done.find({fn, dev});
+  if (it != done.end() && it->second >= bytes) return 0;
+  GCV_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done[{fn, dev}] = bytes;
+  return 0;
+}
+
 hipEvent_t Profiler::get_event() {
   if (next_event == pool.size()) {
     hipEvent_t e;

@@ -127,6 +127,11 @@ const char* get_error();
     if (!(dst)) { ::gcv::set_error("hipMalloc/upload failed for " #dst); return -5; } \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is an attribute of a (function, device) pair: set it once per device,
+// under a lock (several handles on several GPUs may live in one process; launchers can be called from any thread)
+int ensure_dynamic_lds(const void* fn, int bytes);
+#define GCV_ENSURE_LDS(fn, bytes) GCV_TRY(::gcv::ensure_dynamic_lds((const void*)(fn), (int)(bytes)))
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

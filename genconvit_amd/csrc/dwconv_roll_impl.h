@@ -19,16 +19,7 @@ static int launch_dw_roll_cfg(const T* x, const float* wdw, const float* bdw, co
                               int nimg, int H, float eps, hipStream_t s) {
   constexpr int NT = DwRollLds<T, C, NS>::NT;
   constexpr int LDS = DwRollLds<T, C, NS>::bytes;
-  static bool attr_set[64] = {};                       // per device: the LDS opt-in is a per-device function attribute
-  if (LDS > 64 * 1024) {
-    int dev = 0;
-    GCV_CHECK_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-      GCV_CHECK_HIP(hipFuncSetAttribute((const void*)dwconv7_ln_roll_kernel<T, C, NS>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-      if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
-  }
+  if (LDS > 64 * 1024) GCV_ENSURE_LDS((dwconv7_ln_roll_kernel<T, C, NS>), LDS);
   // bands: enough workgroups to fill 256 CUs, never fewer than 7 output rows per band unless the image itself is
   // smaller (each band re-reads a 6-row input apron)
   static const int force_bands = dw_env_int("GCV_DW_BANDS", 0);

@@ -46,11 +46,7 @@ template <typename T> int launch_pack_w2_chunks(const float* w2_dev, T* out, int
 
 template <typename T, int C, int NW> static int launch_mlp_c(const MlpArgs& a, hipStream_t s) {
   constexpr int SMEM = MlpSmem<T, C, NW>::bytes;
-  static bool attr_done = false;
-  if (!attr_done) {
-    GCV_CHECK_HIP(hipFuncSetAttribute((const void*)fused_mlp_kernel<T, C, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    attr_done = true;
-  }
+  GCV_ENSURE_LDS((fused_mlp_kernel<T, C, NW>), SMEM);
   hipLaunchKernelGGL((fused_mlp_kernel<T, C, NW>), dim3(cdiv(a.M, NW * 32)), dim3(NW * 64), SMEM, s, a);
   GCV_CHECK_HIP(hipGetLastError());
   return 0;
@@ -58,11 +54,7 @@ template <typename T, int C, int NW> static int launch_mlp_c(const MlpArgs& a, h
 
 template <typename T> int launch_fused_mlp_res(const MlpArgs& a, hipStream_t s) {
   constexpr int SMEM = MlpResSmem::bytes;
-  static bool attr_done = false;
-  if (!attr_done) {
-    GCV_CHECK_HIP(hipFuncSetAttribute((const void*)fused_mlp_res_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    attr_done = true;
-  }
+  GCV_ENSURE_LDS((fused_mlp_res_kernel<T>), SMEM);
   static const int nw = [] { const char* e = std::getenv("GCV_MLP_RES_WAVES"); return e ? std::atoi(e) : 8; }();
   const int wave_tiles = cdiv(a.M, 32);
   const int nwg = cdiv(wave_tiles, nw) < 256 ? cdiv(wave_tiles, nw) : 256;    // one persistent workgroup per CU
@@ -73,11 +65,7 @@ template <typename T> int launch_fused_mlp_res(const MlpArgs& a, hipStream_t s) 
 
 template <typename T, int C> static int launch_mlp_ring_c(const MlpArgs& a, hipStream_t s) {
   constexpr int SMEM = MlpRingSmem<C>::bytes;
-  static bool attr_done = false;
-  if (!attr_done) {
-    GCV_CHECK_HIP(hipFuncSetAttribute((const void*)fused_mlp_ring_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    attr_done = true;
-  }
+  GCV_ENSURE_LDS((fused_mlp_ring_kernel<T, C>), SMEM);
   const int ntiles = cdiv(a.M, 128);
   const int slots = 256 * (C == 192 ? 2 : 1);              // persistent workgroups: two per CU at C = 192
   hipLaunchKernelGGL((fused_mlp_ring_kernel<T, C>), dim3(ntiles < slots ? ntiles : slots), dim3(256), SMEM, s, a, ntiles);

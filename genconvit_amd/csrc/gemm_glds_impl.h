@@ -8,12 +8,7 @@ namespace gcv {
 
 template <typename T, int EPI, int ACT, int BKB> static int launch_glds_bkb(const GemmArgs& g, hipStream_t s) {
   constexpr int SMEM = GldsSmem<T, BKB>::bytes;
-  static bool attr_done = false;
-  if (!attr_done) {
-    GCV_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_glds_kernel<T, EPI, ACT, BKB>,
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    attr_done = true;
-  }
+  GCV_ENSURE_LDS((gemm_glds_kernel<T, EPI, ACT, BKB>), SMEM);
   const int ntm = cdiv(g.M, kGldsBM), ntn = g.N / kGldsBN;
   hipLaunchKernelGGL((gemm_glds_kernel<T, EPI, ACT, BKB>), dim3(ntm * ntn), dim3(256), SMEM, s, g);
   GCV_CHECK_HIP(hipGetLastError());

@@ -8,13 +8,7 @@ namespace gcv {
 template <typename T, int BM, int BN, int WM, int WN, int BKB, int AMODE, int EPI, int ACT>
 static int launch_cfg(const GemmArgs& g, hipStream_t s) {
   constexpr int SMEM = GemmSmem<T, BM, BN, BKB, EPI>::bytes;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (SMEM > 64 * 1024)
-      GCV_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_kernel<T, BM, BN, WM, WN, BKB, AMODE, EPI, ACT>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM));
-    attr_done = true;
-  }
+  if (SMEM > 64 * 1024) GCV_ENSURE_LDS((gemm_kernel<T, BM, BN, WM, WN, BKB, AMODE, EPI, ACT>), SMEM);
   const int ntm = cdiv(g.M, BM), ntn = cdiv(g.N, BN);
   dim3 grid(ntm * ntn, EPI == EPI_SPLITK ? g.splitk : 1, 1);
   hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, BKB, AMODE, EPI, ACT>), grid, dim3(256), SMEM, s, g);

@@ -25,13 +25,7 @@ static int launch_dw_c(const T* x, const float* wdw, const float* bdw, const flo
   constexpr int TILES = (C == 96) ? 2 : 1;
   constexpr int TPB = C * TILES;
   constexpr size_t LDS = (size_t)TILES * 49 * C * 4 + (size_t)TILES * 49 * 2 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (LDS > 64 * 1024)
-      GCV_CHECK_HIP(hipFuncSetAttribute((const void*)dwconv7_ln_kernel<T, C>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-    attr_set = true;
-  }
+  if (LDS > 64 * 1024) GCV_ENSURE_LDS((dwconv7_ln_kernel<T, C>), LDS);
   const int tiles = nimg * cdiv(H, 7) * cdiv(W, 7);
   hipLaunchKernelGGL((dwconv7_ln_kernel<T, C>), dim3(cdiv(tiles, TILES)), dim3(TPB), LDS, s, x, wdw, bdw, lnw, lnb, y,
                      nimg, H, W, eps);

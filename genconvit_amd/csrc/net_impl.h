@@ -323,14 +323,16 @@ template <typename T> struct NetImpl : NetBase {
           if (C <= 192 || (C == 384 && use_fused_mlp384)) {   // stages with a fused MLP kernel in use
             std::vector<float> v;
             GCV_TRY(fetch(w, b + "mlp.fc2.weight", (int64_t)4 * C * C, v));
-            float* tmp = nullptr;
-            GCV_CHECK_HIP(hipMalloc((void**)&tmp, v.size() * 4));
-            GCV_CHECK_HIP(hipMemcpy(tmp, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+            struct DevBuf {                        // freed on every exit path
+              float* p = nullptr;
+              ~DevBuf() { if (p) (void)hipFree(p); }
+            } tmp;
+            GCV_CHECK_HIP(hipMalloc((void**)&tmp.p, v.size() * 4));
+            GCV_CHECK_HIP(hipMemcpy(tmp.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
             k.fc2_wc = (T*)st.raw(v.size() * sizeof(T));
             if (!k.fc2_wc) { set_error("hipMalloc failed for packed fc2"); return -5; }
-            GCV_TRY(launch_pack_w2_chunks<T>(tmp, k.fc2_wc, C, nullptr));
+            GCV_TRY(launch_pack_w2_chunks<T>(tmp.p, k.fc2_wc, C, nullptr));
             GCV_CHECK_HIP(hipDeviceSynchronize());
-            GCV_CHECK_HIP(hipFree(tmp));
           }
         }
         GCV_TRY(up_f32(w, b + "mlp.fc2.bias", C, st, k.fc2_b));

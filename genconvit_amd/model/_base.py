@@ -43,6 +43,7 @@ OFF_PATH_MARKERS = ("embedder.", "patch_embed.", "num_batches_tracked")
 # They stay host-resident (``.to(device)`` / ``.cuda()`` change only their dtype), are packed into the handle
 # tensor by tensor (descriptor ``on_device = 0``), and ``state_dict()`` keeps returning them under the reference's keys.
 HOST_RESIDENT_NUMEL = 1 << 24
+MAX_HANDLE_BATCH = 512          # gcv_create's upper bound for max_batch
 
 
 class HipModule(nn.Module):
@@ -56,6 +57,8 @@ class HipModule(nn.Module):
         self._handle_key = None
         self._dirty = True
         self._max_batch = self._default_max_batch
+        self._sig_params = None
+        self._loaded_sig = None
 
     # nn.Module._apply is what .to()/.half()/.float()/.cuda() go through
     def _apply(self, fn, *a, **k):
@@ -91,7 +94,20 @@ class HipModule(nn.Module):
     def _load_into(self, handle):   # subclasses push their weights
         raise NotImplementedError
 
+    def invalidate(self):
+        """Force the packed device copy to be rebuilt at the next forward: needed after edits the version check cannot
+        see — writes through ``p.data`` and re-assigned Parameters (``module.fc.weight = nn.Parameter(...)``)."""
+        self._dirty = True
+
+    def _weights_signature(self):
+        # in-place edits (p.mul_(), optimizer-style writes) bump ``_version``; re-assigned Parameters change identity
+        ps = self._sig_params
+        if ps is None:
+            ps = self._sig_params = list(self.parameters()) + list(self.buffers())
+        return (sum(p._version for p in ps), sum(p.data_ptr() for p in ps) & 0xFFFFFFFFFFFF)
+
     def _get_handle(self, batch: int):
+        batch = min(batch, MAX_HANDLE_BATCH)
         device, dtype = self._param_device_dtype()
         if device.type != "cuda":
             raise _lib.GenConViTHipError(
@@ -106,14 +122,22 @@ class HipModule(nn.Module):
             self._handle = _lib.Handle(key[0], dtype, self._max_batch)
             self._handle_key = key
             self._dirty = True
+        if not self._dirty and self._weights_signature() != self._loaded_sig:
+            self._dirty = True                         # a parameter was edited in place or replaced since the last pack
         if self._dirty:
+            self._sig_params = None
             self._load_into(self._handle)
             self._dirty = False
+            self._loaded_sig = self._weights_signature()
         return self._handle
+
+    def _chunks(self, n: int):
+        """Batches beyond one handle's workspace (512 frames) run as consecutive chunks: the reference accepts any B."""
+        return [(i, min(i + MAX_HANDLE_BATCH, n)) for i in range(0, n, MAX_HANDLE_BATCH)]
 
     def reserve(self, max_batch: int):
         """Size the workspace for batches up to ``max_batch`` ahead of the first call."""
-        self._max_batch = max(int(max_batch), 1)
+        self._max_batch = min(max(int(max_batch), 1), MAX_HANDLE_BATCH)
         return self
 
     def _prep_input(self, x):

@@ -87,7 +87,11 @@ class GenConViT(nn.Module):
                                   generator=self.model_vae._generator)
             else:
                 eps = eps.to(device=x.device, dtype=torch.float32)
-            return _lib.genconvit_forward(self.model_ed._get_handle(B), self.model_vae._get_handle(B), x, eps)
+            if B <= 512:
+                return _lib.genconvit_forward(self.model_ed._get_handle(B), self.model_vae._get_handle(B), x, eps)
+            parts = [_lib.genconvit_forward(self.model_ed._get_handle(hi - lo), self.model_vae._get_handle(hi - lo),
+                                            x[lo:hi], eps[lo:hi]) for lo, hi in self.model_ed._chunks(B)]
+            return torch.cat([p[:p.shape[0] // 2] for p in parts] + [p[p.shape[0] // 2:] for p in parts])
         x1 = self.model_ed(x)
         x2 = self.model_vae(x, eps=eps, want_recon=False)[0]
         return torch.cat((x1, x2), dim=0)

@@ -34,6 +34,8 @@ class GenConViTED(HipModule):
         images = self._prep_input(images)
         if images.shape[0] == 0:                      # an empty batch is an empty result, as with the reference's nn.Modules
             return torch.empty((0, 2), dtype=torch.float32, device=images.device)
+        if images.shape[0] > 512:
+            return torch.cat([self._get_handle(hi - lo).ed_forward(images[lo:hi]) for lo, hi in self._chunks(images.shape[0])])
         return self._get_handle(images.shape[0]).ed_forward(images)
 
     def backbone_forward(self, images):

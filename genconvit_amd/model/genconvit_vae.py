@@ -48,7 +48,13 @@ class GenConViTVAE(HipModule):
             eps = torch.randn((B, self.latent_dims), dtype=torch.float32, device=x.device, generator=self._generator)
         else:
             eps = eps.to(device=x.device, dtype=torch.float32)
-        logits, recon, mse, kl = self._get_handle(B).vae_forward(x, eps, want_recon, want_mse, want_kl)
+        if B > 512:                                   # beyond one handle's workspace: consecutive chunks (kl: last chunk's)
+            parts = [self._get_handle(hi - lo).vae_forward(x[lo:hi], eps[lo:hi], want_recon, want_mse, want_kl)
+                     for lo, hi in self._chunks(B)]
+            cat = lambda i: torch.cat([p[i] for p in parts]) if parts[0][i] is not None else None
+            logits, recon, mse, kl = cat(0), cat(1), cat(2), parts[-1][3]
+        else:
+            logits, recon, mse, kl = self._get_handle(B).vae_forward(x, eps, want_recon, want_mse, want_kl)
         self.kl = kl[0] if kl is not None else None
         self.mse = mse
         return logits, recon

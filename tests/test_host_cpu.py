@@ -229,3 +229,77 @@ def test_shard_bounds_cover_and_balance():
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in b]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ----------------------------------------------------------------------------- drop-in claim: the reference's own driver
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "prediction.py")),
+                    reason="the reference checkout only exists in the build container")
+def test_reference_prediction_py_runs_unchanged_on_the_model_alias(tmp_path, monkeypatch, capsys):
+    """alias ``model`` -> ``genconvit_amd.model`` in sys.modules, then import the reference's
+    ``prediction.py`` IN PLACE (never copied) and drive ``vids()`` / ``predict()`` (prediction.py:12-47,231-266) with
+    ``df_face`` replaced by synthetic crops and the forward stubbed (no GPU here).  Checks the star-import surface
+    (``torch`` / ``os`` reach prediction.py through ``from model.pred_func import *``), the ``store_result`` schema
+    and that a per-video exception is printed and swallowed like the reference does."""
+    import importlib.util
+    import json
+    import genconvit_amd.model as gm
+    from genconvit_amd import spec, synth
+    names = ("config", "genconvit", "genconvit_ed", "genconvit_vae", "model_embedder", "pred_func")
+    saved = {k: sys.modules.get(k) for k in ["model"] + [f"model.{n}" for n in names]}
+    try:
+        sys.modules["model"] = gm
+        for n in names:
+            sys.modules[f"model.{n}"] = __import__(f"genconvit_amd.model.{n}", fromlist=["_"])
+        monkeypatch.chdir(tmp_path)                      # weight/, model/config.yaml and result/ are cwd-relative
+        (tmp_path / "weight").mkdir()
+        (tmp_path / "result").mkdir()
+        (tmp_path / "vids").mkdir()
+        torch.save({"state_dict": synth.make_state_dict(spec.ed_spec(), 7, "ed/")}, tmp_path / "weight" / "ed_w.pth")
+        for n in ("a.mp4", "b.avi", "broken.mp4", "notes.txt"):
+            (tmp_path / "vids" / n).write_bytes(b"0")
+        specm = importlib.util.spec_from_file_location("ref_prediction", os.path.join(REFERENCE, "prediction.py"))
+        pred = importlib.util.module_from_spec(specm)
+        specm.loader.exec_module(pred)                   # runs `from model.pred_func import *` + load_config()
+        assert pred.config["model"]["backbone"] == "convnext_tiny"
+        for name in ("load_genconvit", "df_face", "pred_vid", "is_video", "set_result", "store_result", "real_or_fake",
+                     "torch", "os"):
+            assert hasattr(pred, name), f"prediction.py did not receive `{name}` from the star import"
+
+        calls = []
+
+        def fake_df_face(vid, num_frames, net):
+            calls.append(os.path.basename(vid))
+            if "broken" in vid:
+                raise RuntimeError("decoder exploded")
+            return synth.make_frames(3, name=os.path.basename(vid))
+
+        def fake_forward(self, x, eps=None):             # stands in for the HIP forward (no GPU in this container)
+            return torch.tensor([[2.0, -1.0]] * x.shape[0])
+
+        from genconvit_amd.model.genconvit import GenConViT
+        monkeypatch.setattr(pred, "df_face", fake_df_face)
+        monkeypatch.setattr(GenConViT, "forward", fake_forward)
+        result = pred.vids("ed_w", "unused_vae", str(tmp_path / "vids"), "other", 15, "ed", False)
+        out = capsys.readouterr().out
+        assert "An error occurred: decoder exploded" in out              # prediction.py:44-45 swallows per video
+        assert "Invalid video file" in out                               # notes.txt
+        v = result["video"]
+        assert sorted(v["name"]) == ["a.mp4", "b.avi"] and sorted(calls) == ["a.mp4", "b.avi", "broken.mp4"]
+        assert set(v) == {"name", "pred", "klass", "pred_label", "correct_label"}
+        assert v["klass"] == ["uncategorized"] * 2 and v["correct_label"] == ["unknown"] * 2
+        assert v["pred_label"] == ["FAKE", "FAKE"]                       # index 0 = FAKE (pred_func.py:134-135)
+        assert all(abs(p - float(torch.sigmoid(torch.tensor(2.0)))) < 1e-6 for p in v["pred"])
+        json.dumps(result)                                               # what main() writes to result/*.json
+        # predict() with an empty face list: the (0, 0.5) default of prediction.py:252-254
+        monkeypatch.setattr(pred, "df_face", lambda vid, n, net: [])
+        r2, acc, count, p = pred.predict("x.mp4", None, False, pred.set_result(), 15, "ed", "uncategorized")
+        assert p == [0, 0.5] and r2["video"]["pred_label"] == ["FAKE"]   # y = 0 -> {0: "REAL", 1: "FAKE"}[0 ^ 1]
+    finally:
+        for k, m in saved.items():
+            if m is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = m

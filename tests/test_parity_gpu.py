@@ -489,3 +489,22 @@ def test_rccl_allgather_through_the_c_abi_world_size_1():
         gdist.close_comms()
         if own:
             tdist.destroy_process_group()
+
+
+def test_in_place_weight_edits_and_oversize_batches(sd_ed):
+    """The packed device copy follows in-place edits of the nn.Parameters (the reference's modules would pick them up);
+    a batch beyond one handle's 512-frame workspace runs as consecutive chunks (the reference accepts any B)."""
+    m = GenConViTED(load_config(), init="empty")
+    m.load_state_dict(sd_ed)
+    m = m.to("cuda").eval()
+    x = synth.make_frames(3, name="edit").cuda()
+    a = m(x)
+    m.fc2.bias.add_(1.0)                       # in place: bumps the parameter's version counter
+    b = m(x)
+    assert (b - a - 1.0).abs().max().item() <= 1e-6
+    m.fc2.bias.data.sub_(1.0)                  # through .data: invisible to the version check
+    m.invalidate()
+    assert (m(x) - a).abs().max().item() <= 1e-6
+    xb = synth.make_frames(4, name="edit").cuda().repeat(130, 1, 1, 1)      # 520 frames
+    big = m(xb)
+    assert big.shape == (520, 2) and (big[:4] - big[516:]).abs().max().item() <= 1e-6
