@@ -28,7 +28,8 @@ struct MlpResSmem {
   static constexpr int kB1 = 2 * 384 * kRow;             // 384 floats
   static constexpr int kB2 = kB1 + 384 * 4;              // 96 floats
   static constexpr int kG = kB2 + 96 * 4;                // 96 floats
-  static constexpr int bytes = kG + 96 * 4;              // 149760
+  static constexpr int kCtr = kG + 96 * 4;               // tile counter of the workgroup (one dword)
+  static constexpr int bytes = kCtr + 16;                // 149776
 };
 
 __device__ __forceinline__ int mlp_res_swz(int row, int k16) { return (k16 & ~3) | ((k16 & 3) ^ ((row >> 2) & 3)); }
@@ -71,6 +72,7 @@ __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) 
     float* sf = reinterpret_cast<float*>(smem + MlpResSmem::kB1);
     for (int i = tid; i < 384 + 96 + 96; i += (int)blockDim.x)
       sf[i] = i < 384 ? a.b1[i] : (i < 480 ? a.b2[i - 384] : a.gamma[i - 480]);
+    if (tid == 0) *reinterpret_cast<int*>(smem + MlpResSmem::kCtr) = (int)blockDim.x >> 6;   // slots 0 .. nwaves-1 are taken
   }
   __syncthreads();
   RES_STAMP(11);
@@ -97,9 +99,22 @@ __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) 
 #pragma unroll
     for (int p = 0; p < KP1; ++p) xf[p] = *(const u32x4*)(Xp + mmc * C + 16 * p + 8 * lh);
   };
-  if ((int)blockIdx.x * nwaves + wave < ntiles) load_x((int)blockIdx.x * nwaves + wave);
+  // Tiles are handed out dynamically inside the workgroup: the two waves of a SIMD do not progress at the same rate
+  // (the arbiter serves the older one first: wave 0 finished its static share after 375k cycles, wave 7 after 513k,
+  // alone on its SIMD and therefore at half the vector issue rate for the last quarter).  Slot q of this workgroup
+  // is tile blockIdx * nwaves + q % nwaves + (q / nwaves) * stride — the same set of tiles as the static walk — and a
+  // wave takes its next slot from an LDS counter at the START of a tile, so the next rows can still be prefetched.
+  int* const ctr = reinterpret_cast<int*>(smem + MlpResSmem::kCtr);
+  auto slot_tile = [&](int q) { return (int)blockIdx.x * nwaves + (q % nwaves) + (q / nwaves) * stride; };
+  auto next_slot = [&]() {
+    int q = 0;
+    if (lane == 0) q = atomicAdd(ctr, 1);
+    return __builtin_amdgcn_readfirstlane(q);
+  };
+  if (slot_tile(wave) < ntiles) load_x(slot_tile(wave));
   int titer = 0;
-  for (int tile = (int)blockIdx.x * nwaves + wave; tile < ntiles; tile += stride, ++titer) {
+  for (int tile = slot_tile(wave), tile_next = 0; tile < ntiles; tile = tile_next, ++titer) {
+    tile_next = slot_tile(next_slot());
     if (titer == 2) GCV_STAMP(0);
 #if GCV_MLP_STAMPS
     if (titer == 2 && blockIdx.x < 64 && threadIdx.x == 0) gcv_mlp_stamps[blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memrealtime();
@@ -202,6 +217,15 @@ __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) 
     mfma1(wf, accB);
     __builtin_amdgcn_sched_barrier(0);
     if (titer == 2) GCV_STAMP(1);
+    // residual rows: issued a whole tile ahead of the epilogue that adds them (issued in the tail they cost the
+    // epilogue ~4k cycles of exposed load latency per tile)
+    // (16-byte pieces: lanes 0-31 take channels 16p .. 16p+7 of their row, lanes 32-63 the next eight; the epilogue's
+    // permlane32 swap — its own inverse — hands every lane the two 8-byte halves its accumulator layout wants)
+    u32x4 rres[NO][2];
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) rres[o][pr] = *(const u32x4*)(Rp + mld * C + 32 * o + 16 * pr + 8 * lh);
     gelu(accA, hfA);                                        // h(0)
     read_b1(2, accA);
     read_w1(2, wf);
@@ -217,12 +241,7 @@ __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) 
     if (titer == 2) GCV_STAMP(5);
     // tail: g = NG-1 sits in accB, h(NG-2) in hfA, w2f = W2(NG-2)
     __builtin_amdgcn_sched_barrier(0);
-    if (tile + stride < ntiles) load_x(tile + stride);
-    t4 rres[NO][4];
-#pragma unroll
-    for (int o = 0; o < NO; ++o)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) rres[o][q] = *(const t4*)(Rp + mld * C + 32 * o + 8 * q + 4 * lh);
+    if (tile_next < ntiles) load_x(tile_next);
     __builtin_amdgcn_sched_barrier(0);
     mfma2(w2f, hfA);
     gelu(accB, hfB);
@@ -236,17 +255,35 @@ __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) 
     const float* sB2t = sB2;
     const float* sGt = sG;
     asm volatile("" : "+v"(sB2t), "+v"(sGt));
+    // A row's 16 bytes (o, q) are split over the half-waves (lane lr: channels 8q .. 8q+3, lane lr+32: 8q+4 .. 8q+7).
+    // One v_permlane32_swap per dword of a (q, q+1) pair leaves lanes 0-31 with the 16 contiguous bytes of piece q
+    // and lanes 32-63 with those of piece q+1: six 16-byte stores per tile instead of twelve 8-byte ones (each store
+    // instruction touches 32 rows; the epilogue was 5.6k of a tile's 26k cycles, bound by store issue).
 #pragma unroll
     for (int o = 0; o < NO; ++o)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = 32 * o + 8 * q + 4 * lh;
-        const f32x4 bv = *(const f32x4*)(sB2t + n);
-        const f32x4 gv = *(const f32x4*)(sGt + n);
-        t4 o4;
+      for (int q = 0; q < 4; q += 2) {
+        uint2 pk[2];
+        const u32x4 rw = rres[o][q >> 1];
+        const auto rx = __builtin_amdgcn_permlane32_swap(rw[0], rw[2], false, false);
+        const auto ry = __builtin_amdgcn_permlane32_swap(rw[1], rw[3], false, false);
+        const t4 rr[2] = {__builtin_bit_cast(t4, uint2{rx[0], ry[0]}), __builtin_bit_cast(t4, uint2{rx[1], ry[1]})};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o4[e] = from_f<T>(fmaf(acc2[o][4 * q + e] + bv[e], gv[e], to_f(rres[o][q][e])));
-        if (m < a.M && (!(GCV_MLP_ABLATE & 8) || o4[0] == (T)12345.0f)) *(t4*)(Op + m * C + n) = o4;
+        for (int d = 0; d < 2; ++d) {
+          const int n = 32 * o + 8 * (q + d) + 4 * lh;
+          const f32x4 bv = *(const f32x4*)(sB2t + n);
+          const f32x4 gv = *(const f32x4*)(sGt + n);
+          t4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o4[e] = from_f<T>(fmaf(acc2[o][4 * (q + d) + e] + bv[e], gv[e], to_f(rr[d][e])));
+          pk[d] = __builtin_bit_cast(uint2, o4);
+        }
+        // vdst = piece q, src = piece q+1: lanes 32-63 of pk[0] <-> lanes 0-31 of pk[1]
+        auto sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+        auto sy = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+        const u32x4 w = {sx[0], sy[0], sx[1], sy[1]};
+        const int n16 = 32 * o + 8 * q + 8 * lh;           // lanes 0-31: channels 8q .. 8q+7, lanes 32-63: 8q+8 .. 8q+15
+        if (m < a.M && (!(GCV_MLP_ABLATE & 8) || w[0] == 0x12345u)) *(u32x4*)(Op + m * C + n16) = w;
       }
     if (titer == 2) GCV_STAMP(6);
 #if GCV_MLP_STAMPS
