@@ -11,6 +11,9 @@
  *     never synchronised, by the forward calls
  *   - return value 0 = ok; non-zero = error, text via gcv_last_error() (thread-local)
  *   - a handle owns its packed weights + workspace; not thread-safe; one handle per stream
+ *   - the handle-based calls (gcv_*_forward, gcv_load_*) make the handle's device current for their launches and
+ *     restore the caller's device before returning; the handle-less calls (gcv_vote*, gcv_preprocess, gcv_k_*)
+ *     launch on `stream` as given: the device that owns that stream must be the current one
  *   - frames: (B,3,224,224) NCHW contiguous in the handle's storage dtype, already normalised like
  *     model/pred_func.py:95-108 (preprocess_frame); logits are always fp32 (B,2)
  */

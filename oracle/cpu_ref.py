@@ -26,8 +26,13 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-from genconvit_amd.spec import (CONVNEXT_DEPTHS, CONVNEXT_DIMS, SWIN_DEPTHS, SWIN_DIMS,
-                                SWIN_HEADS)
+# Architecture constants, written out here on purpose: the oracle shares no table with the product it checks
+# (genconvit_amd/spec.py holds the product's copy; tests/test_oracle.py asserts the two agree).
+CONVNEXT_DEPTHS = (3, 3, 9, 3)          # timm convnext_tiny
+CONVNEXT_DIMS = (96, 192, 384, 768)
+SWIN_DEPTHS = (2, 2, 6, 2)              # timm swin_tiny_patch4_window7_224
+SWIN_DIMS = (96, 192, 384, 768)
+SWIN_HEADS = (3, 6, 12, 24)
 
 # --------------------------------------------------------------------------- same-dtype restatement (16-bit storage)
 # "for 16-bit report the delta vs the fp32 oracle and vs a same-dtype CPU restatement".  Inside

@@ -186,3 +186,13 @@ def test_swin_restatement_vs_huggingface():
     theirs = m(pixel_values=x).logits
     assert float((ours - theirs).abs().max()) < 5e-5
     assert float(ours.abs().max()) > 0.5
+
+
+def test_oracle_architecture_constants_are_its_own_and_agree_with_the_product():
+    """oracle/cpu_ref.py must not import its architecture table from the product; the two copies must agree."""
+    import re
+    src = open(cpu_ref.__file__).read()
+    assert not re.search(r"^\s*from genconvit_amd|^\s*import genconvit_amd", src, re.M)
+    assert tuple(cpu_ref.CONVNEXT_DEPTHS) == tuple(spec.CONVNEXT_DEPTHS) and tuple(cpu_ref.CONVNEXT_DIMS) == tuple(spec.CONVNEXT_DIMS)
+    assert tuple(cpu_ref.SWIN_DEPTHS) == tuple(spec.SWIN_DEPTHS) and tuple(cpu_ref.SWIN_DIMS) == tuple(spec.SWIN_DIMS)
+    assert tuple(cpu_ref.SWIN_HEADS) == tuple(spec.SWIN_HEADS)
