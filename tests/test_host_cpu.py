@@ -303,3 +303,42 @@ def test_reference_prediction_py_runs_unchanged_on_the_model_alias(tmp_path, mon
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = m
+
+
+# ----------------------------------------------------------------------------- row N2: host-resident big parameters
+def test_big_parameters_stay_on_the_host_and_follow_the_dtype():
+    """The VAE's 25088x12544 Linear weights (1.26 GB each in fp32) must not be moved to the device as nn.Parameters:
+    `.half()` / `.to(dtype)` change their dtype, `.to(device)` leaves them where they are; every other parameter follows
+    `_apply` as usual and state_dict() keeps the reference's keys."""
+    from genconvit_amd.model import _base
+    from genconvit_amd.model.config import load_config
+    from genconvit_amd.model.genconvit_vae import GenConViTVAE
+    m = GenConViTVAE(load_config(), init="empty")
+    big = [n for n, p in m.named_parameters() if p.numel() >= _base.HOST_RESIDENT_NUMEL]
+    assert sorted(big) == ["encoder.fc1.weight", "encoder.mu.weight", "encoder.var.weight"] or "encoder.mu.weight" in big
+    m.half()
+    sd = m.state_dict()
+    assert sd["encoder.mu.weight"].dtype == torch.float16 and sd["encoder.mu.weight"].device.type == "cpu"
+    assert sd["fc.weight"].dtype == torch.float16
+    assert sd["encoder.mu.weight"].shape == (12544, 25088)
+    dev, dt = m._param_device_dtype()          # device discovery ignores the host-resident tensors
+    assert dt == torch.float16 and dev.type == "cpu"
+    assert m._chunks(1100) == [(0, 512), (512, 1024), (1024, 1100)]
+
+
+def test_same_dtype_restatement_is_the_identity_in_fp32_and_close_in_16_bit():
+    """oracle/cpu_ref.py::storage_dtype — fp32 must leave the pinned oracle bit-for-bit unchanged; fp16 / bf16 round at
+    the HIP path's storage points and stay within the deltas the MI355X shows (tests/test_parity_gpu.py gates on both)."""
+    from genconvit_amd import spec, synth
+    from oracle import cpu_ref
+    sd = synth.make_state_dict(spec.ed_spec(), synth.DEFAULT_SEED, "ed/")
+    x = synth.make_frames(1)
+    base = cpu_ref.ed_forward(sd, x)
+    with cpu_ref.storage_dtype(torch.float32):
+        assert torch.equal(cpu_ref.ed_forward(sd, x), base)
+    with cpu_ref.storage_dtype(torch.float16):
+        d16 = (cpu_ref.ed_forward(sd, x) - base).abs().max().item()
+    with cpu_ref.storage_dtype(torch.bfloat16):
+        db = (cpu_ref.ed_forward(sd, x) - base).abs().max().item()
+    assert cpu_ref._STORE is None                # the context restores the default
+    assert 0 < d16 < 2e-3 and d16 < db < 3e-2, (d16, db)

@@ -1,6 +1,8 @@
 """CPU tests of the oracle (oracle/cpu_ref.py): it must reproduce the committed golden
 vectors (made by the reference's own classes, tests/golden/make_golden.py) and agree with
 the independent Hugging Face implementation of ConvNeXt-T / Swin-T."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -196,3 +198,19 @@ def test_oracle_architecture_constants_are_its_own_and_agree_with_the_product():
     assert tuple(cpu_ref.CONVNEXT_DEPTHS) == tuple(spec.CONVNEXT_DEPTHS) and tuple(cpu_ref.CONVNEXT_DIMS) == tuple(spec.CONVNEXT_DIMS)
     assert tuple(cpu_ref.SWIN_DEPTHS) == tuple(spec.SWIN_DEPTHS) and tuple(cpu_ref.SWIN_DIMS) == tuple(spec.SWIN_DIMS)
     assert tuple(cpu_ref.SWIN_HEADS) == tuple(spec.SWIN_HEADS)
+
+
+def test_committed_huggingface_fixture_is_what_the_script_produces(tmp_path):
+    """tests/golden/hf_backbones.npz must be reproducible from tests/golden/make_hf_golden.py in this container."""
+    import importlib.util
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    s = importlib.util.spec_from_file_location("make_hf_golden", os.path.join(here, "golden", "make_hf_golden.py"))
+    mod = importlib.util.module_from_spec(s)
+    s.loader.exec_module(mod)
+    out = str(tmp_path / "hf.npz")
+    mod.main(out)
+    new, old = dict(np.load(out)), dict(np.load(os.path.join(here, "golden", "hf_backbones.npz")))
+    assert set(new) == set(old)
+    for k in old:
+        assert np.array_equal(new[k], old[k]), k
