@@ -309,7 +309,20 @@ def genconvit_forward(h_ed: "Handle", h_vae: "Handle", x, eps):
 class Comm:
     """RCCL communicator of the C ABI (``gcv_comm_*``): one per process group, used for the logit all-gather."""
 
+    @staticmethod
+    def _share_torch_rccl():
+        """Every rank must bind the SAME RCCL build (the one torch.distributed already uses in this process): point the
+        library's run-time loader at torch's bundled copy unless the caller chose one."""
+        try:
+            import torch
+            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            if os.path.exists(path):
+                os.environ.setdefault("GCV_RCCL_PATH", path)
+        except Exception:
+            pass
+
     def __init__(self, world: int, rank: int, unique_id: bytes, device_index: int):
+        self._share_torch_rccl()
         self.lib = load()
         self.world, self.rank, self.device_index = int(world), int(rank), int(device_index)
         self._c = c_void_p()
@@ -318,11 +331,7 @@ class Comm:
 
     @staticmethod
     def unique_id() -> bytes:
-        try:                  # share torch's RCCL the way the HIP runtime is shared
-            import torch
-            os.environ.setdefault("GCV_RCCL_PATH", os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
-        except Exception:
-            pass
+        Comm._share_torch_rccl()
         buf = ctypes.create_string_buffer(128)
         check(load().gcv_comm_unique_id(buf), "gcv_comm_unique_id")
         return buf.raw

@@ -27,15 +27,28 @@ def _c_comm(group, device):
     if key not in _COMMS:
         from . import _lib
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-        uid = [_lib.Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        _COMMS[key] = _lib.Comm(world, rank, uid[0], device.index if device.index is not None else torch.cuda.current_device())
+        # ncclCommInitRank blocks until every rank has joined: first make sure, over the torch group, that RCCL could be
+        # bound on ALL ranks (each draws a throw-away id as the probe); otherwise every rank keeps torch's all_gather
+        try:
+            uid, ok = _lib.Comm.unique_id(), 1
+        except Exception as e:      # library / symbols missing on this rank
+            uid, ok = None, 0
+            print(f"[genconvit_amd.dist] rank {rank}: RCCL not bound through the C ABI ({e}); using torch.distributed", flush=True)
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 0:
+            _COMMS[key] = None
+        else:
+            box = [uid if rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            _COMMS[key] = _lib.Comm(world, rank, box[0], device.index if device.index is not None else torch.cuda.current_device())
     return _COMMS[key]
 
 
 def close_comms():
     for c in _COMMS.values():
-        c.close()
+        if c is not None:
+            c.close()
     _COMMS.clear()
 
 
