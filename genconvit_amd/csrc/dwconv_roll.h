@@ -7,34 +7,35 @@
 // Why the round-1 kernels sat at 14 % of the HBM roofline with traffic already algorithmic: one workgroup per 7x7
 // tile re-reads a 13x13 halo (3.45x) and pays 104 LDS reads (+ as many packs) for 343 dot2 per thread, five
 // barriers per tile.  This kernel removes the vertical halo altogether:
-//   * one workgroup = a band of rows of one image over its whole width; one THREAD = one channel of a 7-pixel-wide
-//     column strip.  It walks DOWN the band, one input row per step, holding the 7 output rows that are still open
-//     as 49 fp32 accumulators and the 49 taps in registers: an input row of 13 values feeds 7 x 7 x 7 = 343 FMAs
-//     (26 FMAs per value read, against 6.6);
-//   * every byte crosses the vector-memory pipe exactly once, 16 bytes per lane: the workgroup stages input row
-//     r + 1 (one 16-byte piece per thread, issued before the FMAs of row r, written to a two-slot LDS ring after
-//     them) and each thread then picks its 13 values of its channel from LDS; horizontal zero padding is a zeroed
-//     3-pixel apron of the ring, vertical padding = rows that are simply not visited.  (A first version read its 13
-//     values per row straight from global memory, 2 bytes per lane: 156 loads + 84 stores per row and CU took longer
-//     than the 343 FMAs — profiles/r02_dw_ablation.txt.)
-//   * rows above / below the band and taps that fall outside it are skipped by wave-uniform branches, so no FMA is
-//     spent on vertical padding; a strip that spans the whole image width (W = 7) also skips the horizontal padding
-//     taps at compile time (FULLW);
-//   * LayerNorm: the finished output row goes to LDS as [pixel][C] fp32 (three-slot ring); C/12 lanes per pixel
-//     reduce it (local mean / M2 over 12 values, Chan's combination across the lanes by DPP); one step later the row
-//     is normalised piece-wise — each thread takes 16 bytes of output: 8 (4) channels of one pixel — and stored with
-//     one 16-byte store per thread.  ONE workgroup barrier per row.
-// fp32 accumulation, exact fp32 taps, LayerNorm statistics in fp32 for every storage dtype.
+//   * one workgroup = a band of rows of one image over its whole width; one TAP THREAD = one channel of a
+//     7-pixel-wide column strip.  It walks DOWN the band, one input row per step, holding the 7 output rows that are
+//     still open as 49 fp32 accumulators and the 49 taps in registers: an input row of 13 values feeds
+//     7 x 7 x 7 = 343 FMAs (26 FMAs per value read, against 6.6);
+//   * rows above / below the band and tap rows that fall outside it are skipped by wave-uniform branches, so no FMA
+//     is spent on vertical padding; a strip that spans the whole image width (W = 7) also skips the horizontal
+//     padding taps at compile time (FULLW); horizontal padding otherwise = a zeroed 3-pixel apron of the LDS ring;
+//   * specialised waves, ONE workgroup barrier per row.  Threads [0, NS * C) run the taps; a further third of that
+//     many ("staging waves") move every byte across the vector-memory pipe exactly once, 16 bytes per lane: they
+//     load input row it + 3 (a whole step to land), widen it to fp32 into a three-slot LDS ring, and LayerNorm +
+//     store the output row the tap waves finished one step earlier (24 values per lane from a two-slot fp32 LDS
+//     ring, C / 24 lanes per pixel, DPP group reduction).  (A first version read its 13 values per row straight from
+//     global memory, 2 bytes per lane: 156 loads + 84 stores per row and CU took longer than the 343 FMAs —
+//     profiles/r02_dw/v1_*.)
+//   * the tap waves read the 13 values of the NEXT row with inline-asm ds_read_b32 while the current row's FMAs run
+//     and rotate their priority (s_setprio) as they advance through a row's seven tap rows: three waves share a SIMD
+//     and its arbiter would otherwise serve two of them and leave the third to run alone at half rate
+//     (profiles/micro/fmac_banks.hip).
+// fp32 accumulation, exact fp32 taps, LayerNorm statistics in fp32 for every storage dtype.  DESIGN.md section 4 has
+// the measurements and the dead ends.
 #pragma once
 #include "common.h"
 
 namespace gcv {
 
+// per-dtype pieces: EPC elements per 16-byte piece; lo / hi widen the two 16-bit halves of a dword to fp32
 template <typename T> struct DwElem;
 template <> struct DwElem<float> {
-  static constexpr int EPC = 4;                        // elements per 16-byte piece
-  __device__ static __forceinline__ uint32_t pack2(float a, float) { return __builtin_bit_cast(uint32_t, a); }  // unused
-  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  static constexpr int EPC = 4;
   __device__ static __forceinline__ u32x4 pack(const float (&v)[4]) {
     return u32x4{__builtin_bit_cast(uint32_t, v[0]), __builtin_bit_cast(uint32_t, v[1]),
                  __builtin_bit_cast(uint32_t, v[2]), __builtin_bit_cast(uint32_t, v[3])};
@@ -44,37 +45,11 @@ template <> struct DwElem<half_t> {
   static constexpr int EPC = 8;
   __device__ static __forceinline__ float lo(uint32_t v) { return (float)__builtin_bit_cast(_Float16, (uint16_t)v); }
   __device__ static __forceinline__ float hi(uint32_t v) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(v >> 16)); }
-  __device__ static __forceinline__ uint32_t pack2(float a, float b) {
-    return (uint32_t)__builtin_bit_cast(uint16_t, (half_t)a) | ((uint32_t)__builtin_bit_cast(uint16_t, (half_t)b) << 16);
-  }
-  __device__ static __forceinline__ float ld(const half_t* p) { return (float)*p; }
-  __device__ static __forceinline__ u32x4 pack(const float (&v)[8]) {
-    u32x4 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      r[i] = (uint32_t)__builtin_bit_cast(uint16_t, (half_t)v[2 * i]) |
-             ((uint32_t)__builtin_bit_cast(uint16_t, (half_t)v[2 * i + 1]) << 16);
-    return r;
-  }
 };
 template <> struct DwElem<bf16_t> {
   static constexpr int EPC = 8;
   __device__ static __forceinline__ float lo(uint32_t v) { return __builtin_bit_cast(float, v << 16); }
   __device__ static __forceinline__ float hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
-  __device__ static __forceinline__ uint32_t pack2(float a, float b) {
-    return (uint32_t)__builtin_bit_cast(uint16_t, (bf16_t)a) | ((uint32_t)__builtin_bit_cast(uint16_t, (bf16_t)b) << 16);
-  }
-  __device__ static __forceinline__ float ld(const bf16_t* p) {
-    return __builtin_bit_cast(float, (uint32_t)*reinterpret_cast<const uint16_t*>(p) << 16);
-  }
-  __device__ static __forceinline__ u32x4 pack(const float (&v)[8]) {
-    u32x4 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      r[i] = (uint32_t)__builtin_bit_cast(uint16_t, (bf16_t)v[2 * i]) |
-             ((uint32_t)__builtin_bit_cast(uint16_t, (bf16_t)v[2 * i + 1]) << 16);
-    return r;
-  }
 };
 
 template <int L> __device__ __forceinline__ float dw_group_sum(float v) {
