@@ -363,12 +363,14 @@ dwconv7_ln_roll_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*
 #pragma unroll
       for (int j = 0; j < 6; ++j) {
         const int off = (p * C + 4 * (g + L * j)) * (int)sizeof(T);
-        if constexpr (sizeof(T) == 4) {
-          __builtin_amdgcn_raw_buffer_store_b128(pk[j], rsy, off, orow * row_bytes, 0);
-        } else {
-          typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk[j][0], pk[j][1]}, rsy, off, orow * row_bytes, 0);
-        }
+        // 8-byte stores only.  A 16-byte buffer store with an SGPR soffset reads its data registers late and the
+        // compiler's hazard recogniser does not guard that form: VALU writes a few instructions behind it gave stale
+        // dwords in lanes 12-15 of each 16-lane row (fp32 storage; first seen with register reuse right behind the store,
+        // again - dwords 2-3 of the first piece - in an experiment without the row barrier behind the stores).
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk[j][0], pk[j][1]}, rsy, off, orow * row_bytes, 0);
+        if constexpr (sizeof(T) == 4)
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{pk[j][2], pk[j][3]}, rsy, off + 8, orow * row_bytes, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
     };

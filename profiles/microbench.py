@@ -14,7 +14,7 @@ dev = torch.device("cuda", 0)
 lib = _lib.load()
 st = lambda: _lib.current_stream_ptr(dev)
 R = lambda *s: (torch.rand(*s, device=dev) * 2 - 1)
-nimg = 256
+nimg = int(os.environ.get("GCV_MB_NIMG", "256"))
 
 
 def run(fn, flops, bytes_):
