@@ -144,6 +144,129 @@ __global__ void __launch_bounds__(256) stem_ln_kernel(const T* __restrict__ x, i
   }
 }
 
+// ------------------------------------------------------------------ K3 on the matrix pipe (16-bit storage)
+// The stem is a [tokens x 48] x [48 x 96] contraction: 4608 MACs per token cost the vector pipe more than the
+// 288 bytes the token moves.  Here a wave owns 32-token tiles: the patch IS the MFMA operand — a lane's 8 k values of
+// a k-step are two 8-byte pieces of the frame (NCHW: the 4 kx of rows ky, ky+1 of one channel; NHWC: two thirds of
+// the 12 (kx, ci) values of a row), fetched straight into registers one tile ahead — 3 k-steps x 3 channel tiles =
+// 9 MFMAs per tile; the 16-bit weight fragments (k permuted to the frame's memory order) are built once per
+// workgroup in LDS.  LayerNorm runs on the accumulator (token on the lane, the two half-waves hold 48 channels
+// each; two-pass statistics, one v_permlane32_swap per partial), and the store is six 16-byte pieces per lane.
+template <typename T>
+__global__ void __launch_bounds__(256, 3) stem_ln_mfma_kernel(const T* __restrict__ x, int64_t sb, int64_t sc, int64_t sy,
+                                                           int nhwc, const float* __restrict__ wp,
+                                                           const float* __restrict__ bias, const float* __restrict__ lnw,
+                                                           const float* __restrict__ lnb, T* __restrict__ out, int total,
+                                                           int Ho, int Wo, float eps) {
+  static_assert(sizeof(T) == 2, "matrix-pipe stem is built for 16-bit storage");
+  __shared__ __attribute__((aligned(16))) T sWf[9 * 64 * 8];          // [o][p][lane][8]
+  __shared__ __attribute__((aligned(16))) float sPar[3 * 96];         // bias | ln weight | ln bias
+  const int tid = threadIdx.x;
+  for (int idx = tid; idx < 48 * 96; idx += 256) {
+    const int k = idx / 96, n = idx - k * 96;
+    const int ci = k >> 4, ky = (k >> 2) & 3, kx = k & 3;
+    const int kk = nhwc ? ky * 12 + kx * 3 + ci : k;                  // position in the frame's memory order
+    const int o = n >> 5, lr = n & 31, p = kk >> 4, lh = (kk >> 3) & 1, i = kk & 7;
+    sWf[((o * 3 + p) * 64 + lh * 32 + lr) * 8 + i] = from_f<T>(wp[idx]);
+  }
+  for (int i = tid; i < 3 * 96; i += 256) sPar[i] = i < 96 ? bias[i] : (i < 192 ? lnw[i - 96] : lnb[i - 192]);
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  u32x4 wf[3][3];
+#pragma unroll
+  for (int o = 0; o < 3; ++o)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) wf[o][p] = *reinterpret_cast<const u32x4*>(sWf + ((o * 3 + p) * 64 + lane) * 8);
+
+  const int ntiles = (total + 31) / 32;
+  const int stride = (int)gridDim.x * 4;
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  typedef T t4 __attribute__((ext_vector_type(4)));
+  u32x2 xf[3][2];
+  auto load_x = [&](int tile) {
+    const int gp = min(tile * 32 + lr, total - 1);         // tail rows recompute the last token, store nothing
+    const int xo = gp % Wo, t = gp / Wo;
+    const int yo = t % Ho, b = t / Ho;
+    const T* base = x + (int64_t)b * sb + (int64_t)(4 * yo) * sy;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const T* src;
+        if (nhwc) {
+          const int j = 4 * p + 2 * lh + h;                // piece j of the 12: row ky = j / 3, third j % 3
+          const int ky = j / 3, th = j - 3 * ky;
+          src = base + (int64_t)ky * sy + 12 * xo + 4 * th;
+        } else {
+          src = base + (int64_t)p * sc + (int64_t)(2 * lh + h) * sy + 4 * xo;
+        }
+        xf[p][h] = *reinterpret_cast<const u32x2*>(src);
+      }
+  };
+  int tile = (int)blockIdx.x * 4 + wave;
+  if (tile < ntiles) load_x(tile);
+  for (; tile < ntiles; tile += stride) {
+    const float* sp = sPar;                                // (through an empty asm: the parameter reads stay in the loop
+    asm volatile("" : "+v"(sp));                           //  instead of 144 hoisted registers)
+    f32x16 acc[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(sp + 32 * o + 8 * q + 4 * lh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[o][4 * q + e] = bv[e];
+      }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const u32x4 xv = {xf[p][0][0], xf[p][0][1], xf[p][1][0], xf[p][1][1]};
+#pragma unroll
+      for (int o = 0; o < 3; ++o) Mfma<T>::run(wf[o][p], xv, acc[o]);
+    }
+    if (tile + stride < ntiles) load_x(tile + stride);      // lands under the LayerNorm and the stores
+    // LayerNorm over the token's 96 channels: 48 on this lane, 48 on lane ^ 32
+    // (ds_bpermute, not v_permlane32_swap: with one value as both operands hipcc 7.2 folds the two results into one
+    // register and adds it to itself)
+    auto both = [&](float v) { return v + __shfl_xor(v, 32, 64); };
+    float s = 0.0f;
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[o][r];
+    const float mean = both(s) * (1.0f / 96.0f);
+    float qq = 0.0f;
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const float d = acc[o][r] - mean; qq = fmaf(d, d, qq); }
+    const float rstd = 1.0f / sqrtf(both(qq) * (1.0f / 96.0f) + eps);
+    const int m = tile * 32 + lr;
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+      for (int q = 0; q < 4; q += 2) {
+        uint2 pk[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const int n = 32 * o + 8 * (q + d) + 4 * lh;
+          const f32x4 lw4 = *reinterpret_cast<const f32x4*>(sp + 96 + n);
+          const f32x4 lb4 = *reinterpret_cast<const f32x4*>(sp + 192 + n);
+          t4 o4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o4[e] = from_f<T>(fmaf((acc[o][4 * (q + d) + e] - mean) * rstd, lw4[e], lb4[e]));
+          pk[d] = __builtin_bit_cast(uint2, o4);
+        }
+        // lanes 32-63 of piece q <-> lanes 0-31 of piece q+1: every lane ends up with 16 contiguous bytes
+        const auto sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+        const auto sy2 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+        const u32x4 w = {sx[0], sy2[0], sx[1], sy2[1]};
+        if (m < total) *reinterpret_cast<u32x4*>(out + (int64_t)m * 96 + 32 * o + 8 * q + 8 * lh) = w;
+      }
+  }
+}
+
 // ------------------------------------------------------------------ K4: dwconv7x7 + LN (generic tile kernel)
 // The ConvNeXt-T shapes with W % 7 == 0 run the rolling-strip kernel of dwconv_roll.h; this one covers the rest
 // (the 3x3 map of the 112-px pass).

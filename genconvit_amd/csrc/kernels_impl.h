@@ -1,5 +1,6 @@
 // Launch wrappers for kernels.h (included by kern_{f32,f16,bf16}.hip).
 #pragma once
+#include <algorithm>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -13,6 +14,21 @@ int launch_stem_ln(const T* x, int64_t sb, int64_t sc, int64_t sy, int64_t sx, c
   const int64_t total = (int64_t)nimg * Ho * Wo;
   GCV_REQUIRE(total > 0, "stem: empty");
   GCV_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15u) == 0, "stem: packed weights must be 16-byte aligned");
+  if constexpr (sizeof(T) == 2) {
+    // matrix-pipe stem: the two frame layouts of the path with 8-byte aligned patch pieces (GCV_STEM_VALU=1: A/B switch)
+    static const bool valu = std::getenv("GCV_STEM_VALU") != nullptr;
+    const bool al = (reinterpret_cast<uintptr_t>(x) & 7u) == 0 && ((sb | sy) & 3) == 0 &&
+                    (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+    const bool nchw4 = al && sx == 1 && (sc & 3) == 0, nhwc4 = al && sc == 1 && sx == 3;
+    if (!valu && (nchw4 || nhwc4) && total < (int64_t)1 << 30) {
+      const int ntiles = (int)cdiv64(total, 32);
+      const int grid = std::min(cdiv(ntiles, 4), 256 * 8);
+      hipLaunchKernelGGL((stem_ln_mfma_kernel<T>), dim3(grid), dim3(256), 0, s, x, sb, sc, sy, nhwc4 ? 1 : 0, wp, bias, lnw,
+                         lnb, out, (int)total, Ho, Wo, eps);
+      GCV_CHECK_HIP(hipGetLastError());
+      return 0;
+    }
+  }
   hipLaunchKernelGGL((stem_ln_kernel<T>), dim3((unsigned)cdiv64(total, kStemTok)), dim3(256), 0, s, x, sb, sc, sy, sx, wp,
                      bias, lnw, lnb, out, nimg, Ho, Wo, eps);
   GCV_CHECK_HIP(hipGetLastError());

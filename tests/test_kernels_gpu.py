@@ -152,7 +152,7 @@ def test_stem_conv4x4_layernorm(dt, layout, res):
     dtype = DTYPES[dt]
     n = 2
     x = q(rnd((n, 3, res, res), 1, 2.0), dtype)
-    w = rnd((96, 3, 4, 4), 2, 0.2)
+    w = q(rnd((96, 3, 4, 4), 2, 0.2), dtype)          # 16-bit storage runs the stem on the matrix pipe: 16-bit weights
     b, lw, lb = rnd((96,), 3, 0.1), rnd((96,), 4, 0.5) + 1.0, rnd((96,), 5, 0.1)
     y = F.conv2d(x, w, b, stride=4).permute(0, 2, 3, 1)
     want = F.layer_norm(y, (96,), lw, lb, 1e-6)
