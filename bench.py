@@ -272,7 +272,7 @@ def main():
         bound = "mfma" if name.startswith("mfma_gemm") or "gemm" in name else "hbm"
         roof = entry(name, d, bound, "mfma_gemm" if name == mfma_name else ("dwconv7_ln" if "dwconv" in name else None))
         roof["breakdown_ms_per_step"] = {k: round(v["ms"] / max(a.profile_steps, 1), 3)
-                                         for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+                                         for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:16]}
         # north_star: "achieved HBM GB/s for the depthwise/window-attention kernels and MFMA utilisation for the
         # pointwise GEMMs": one entry per kernel family of the step (the dominant one is `roofline` above)
         families = []

@@ -60,6 +60,7 @@ SIGNATURES = {
     "gcv_swin_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "gcv_vote": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "gcv_preprocess": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "gcv_face_crop_resize": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "gcv_vote_segments": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "gcv_profile_enable": (c_int, [c_void_p, c_int]),
     "gcv_profile_report": (c_char_p, [c_void_p]),
@@ -370,6 +371,32 @@ def preprocess(frames_u8, dtype=None):
     out = torch.empty((n, 3, h, w), dtype=dtype, device=frames_u8.device)
     check(lib.gcv_preprocess(dtype_code(dtype), frames_u8.data_ptr(), out.data_ptr(), n, h, w,
                              current_stream_ptr(frames_u8.device)), "gcv_preprocess")
+    return out
+
+
+def face_crop_resize(frames_u8, boxes, size=224):
+    """Row N4: ``cv2.resize(frame[top:bottom, left:right], (size, size), interpolation=cv2.INTER_AREA)`` of face_rec
+    (model/pred_func.py:79-85) for all boxes in one launch.  ``frames_u8``: (F,H,W,3) uint8 device tensor (RGB);
+    ``boxes``: (n,5) integers (frame index, top, right, bottom, left).  Returns (n,size,size,3) uint8 on the device.
+    Boxes outside their frame are an error here (the kernel itself would write zeros for them)."""
+    import torch
+    lib = load()
+    if not (frames_u8.is_cuda and frames_u8.dtype == torch.uint8 and frames_u8.dim() == 4 and frames_u8.shape[3] == 3):
+        raise GenConViTHipError("face_crop_resize expects a uint8 device tensor of shape (F,H,W,3)")
+    frames_u8 = frames_u8.contiguous()
+    nf, h, w, _ = frames_u8.shape
+    b = torch.as_tensor(boxes, dtype=torch.int32).reshape(-1, 5).cpu()
+    if b.numel():
+        f, top, right, bottom, left = b.unbind(1)
+        ok = (f >= 0) & (f < nf) & (top >= 0) & (left >= 0) & (bottom <= h) & (right <= w) & (top < bottom) & (left < right)
+        if not bool(ok.all()):
+            raise GenConViTHipError(f"face_crop_resize: box {int((~ok).nonzero()[0])} lies outside its {h}x{w} frame")
+    out = torch.empty((b.shape[0], size, size, 3), dtype=torch.uint8, device=frames_u8.device)
+    if b.shape[0] == 0:
+        return out
+    bd = b.to(frames_u8.device)
+    check(lib.gcv_face_crop_resize(frames_u8.data_ptr(), nf, h, w, bd.data_ptr(), b.shape[0], out.data_ptr(), size,
+                                   current_stream_ptr(frames_u8.device)), "gcv_face_crop_resize")
     return out
 
 

@@ -413,6 +413,13 @@ int gcv_preprocess(int dtype, const void* frames_u8_nhwc, void* out_nchw, int n,
   DISPATCH_DT(dtype, launch_preprocess<T>((const unsigned char*)frames_u8_nhwc, (T*)out_nchw, n, H, W, (hipStream_t)s));
 }
 
+int gcv_face_crop_resize(const void* frames_u8_nhwc, int nframes, int H, int W, const int* boxes5, int n,
+                         void* out_u8_nhwc, int size, gcv_stream s) {
+  GCV_REQUIRE(frames_u8_nhwc && out_u8_nhwc && (boxes5 || n == 0), "face crop: null pointer");
+  return launch_face_crop_resize((const unsigned char*)frames_u8_nhwc, nframes, H, W, boxes5, n, (unsigned char*)out_u8_nhwc,
+                                 size, (hipStream_t)s);
+}
+
 // fused ConvNeXt MLP (16-bit only): W2 is given as plain (C,4C) fp32 on the device and packed here
 int gcv_k_fused_mlp(int dtype, int C, const void* x, const void* w1, const float* b1, const float* w2_f32,
                     const float* b2, const float* gamma, const void* resid, void* out, int M, gcv_stream s) {

@@ -50,6 +50,9 @@ template <typename T> int launch_patch_merge_ln(const T* x, const float* w, cons
                                                 int W, int C, float eps, hipStream_t s);
 template <typename T> int launch_mean_tokens(const T* x, T* out, int nimg, int L, int C, hipStream_t s);
 template <typename T> int launch_preprocess(const unsigned char* u8, T* out, int n, int H, int W, hipStream_t s);
+// N4 (face.hip): crop + cv2.INTER_AREA resize of n face boxes, uint8 RGB
+int launch_face_crop_resize(const unsigned char* frames, int nframes, int H, int W, const int* boxes5, int n,
+                            unsigned char* out, int S, hipStream_t s);
 int launch_kl(const float* partial, int splitk, const float* bias, const float* mu, float* rowsum, float* kl, int B,
               int N, hipStream_t s);
 int launch_vote(const float* logits, int rows, float* mean2, hipStream_t s);

@@ -4,8 +4,9 @@ Same names and argument meaning (``load_genconvit``, ``preprocess_frame``, ``pre
 ``max_prediction_value``, ``real_or_fake``, ``df_face``, ``face_rec``, ``extract_frames``,
 ``is_video``, ``set_result``, ``store_result``).  ``prediction.py`` star-imports this module and
 relies on ``torch``/``os``/``np`` coming along, so they stay module globals.  The heavy CPU-side
-dependencies (cv2, dlib, face_recognition, decord) are imported lazily inside the video / face
-functions so the model path imports on a box without them.
+dependencies (dlib, face_recognition, decord) are imported lazily inside the video / face
+functions so the model path imports on a box without them; cv2 is not needed any more (the crop +
+INTER_AREA resize of ``face_rec`` runs on the device, row N4).
 """
 import os
 
@@ -107,22 +108,37 @@ def extract_frames(video_file, frames_nums=15):
     return vr.get_batch(list(range(0, len(vr), step_size))[:frames_nums]).asnumpy()
 
 
-def face_rec(frames, p=None, klass=None):
-    import cv2
+def face_locations(frames):
+    """The detector call of the reference's face_rec (:71-76): dlib's CNN / HOG detector through ``face_recognition``
+    on the CPU (third-party; imported lazily).  Returns rows (frame index, top, right, bottom, left), at most
+    ``len(frames)`` of them in frame order — the reference stops filling ``temp_face`` there (:78,88-89)."""
     import dlib
     import face_recognition
-    temp_face = np.zeros((len(frames), 224, 224, 3), dtype=np.uint8)
-    count = 0
     mod = "cnn" if dlib.DLIB_USE_CUDA else "hog"
-    for frame in frames:
-        frame = cv2.cvtColor(frame, cv2.COLOR_RGB2BGR)
-        for (top, right, bottom, left) in face_recognition.face_locations(frame, number_of_times_to_upsample=0, model=mod):
-            if count >= len(frames):
-                break
-            face_image = cv2.resize(frame[top:bottom, left:right], (224, 224), interpolation=cv2.INTER_AREA)
-            temp_face[count] = cv2.cvtColor(face_image, cv2.COLOR_BGR2RGB)
-            count += 1
-    return ([], 0) if count == 0 else (temp_face[:count], count)
+    boxes = []
+    for i, frame in enumerate(frames):
+        bgr = np.ascontiguousarray(frame[..., ::-1])          # cv2.cvtColor(frame, cv2.COLOR_RGB2BGR) (:72)
+        for loc in face_recognition.face_locations(bgr, number_of_times_to_upsample=0, model=mod):
+            if len(boxes) < len(frames):
+                boxes.append((i, *loc))
+    return boxes
+
+
+def crop_faces(frames, boxes, size=224):
+    """Row N4: crop + ``cv2.INTER_AREA`` resize of every box on the MI355X (``gcv_face_crop_resize``); the RGB<->BGR
+    swaps the reference wraps around the resize (:72,86) cancel.  uint8 (n,size,size,3) on the device."""
+    fr = torch.as_tensor(np.ascontiguousarray(frames)).to(device)
+    return _lib.face_crop_resize(fr, boxes, size)
+
+
+def face_rec(frames, p=None, klass=None, locate=None):
+    """reference :67-92.  Detection stays third-party CPU code (``locate``, default ``face_locations`` above); the crops
+    are cut and resized on the device and come back as the uint8 array the reference returns."""
+    boxes = (locate or face_locations)(frames)
+    if len(boxes) == 0:
+        return [], 0
+    boxes = boxes[:len(frames)]
+    return crop_faces(frames, boxes).cpu().numpy(), len(boxes)
 
 
 def df_face(vid, num_frames, net):

@@ -101,6 +101,16 @@ int gcv_swin_forward(gcv_handle* h, const void* x_nchw, int batch, void* logits1
  * uint8 NHWC face crops (n,H,W,3) -> ((x/255) - mean) / std as NCHW in `dtype` (row N1 of SURVEY.md §8f). */
 int gcv_preprocess(int dtype, const void* frames_u8_nhwc, void* out_nchw, int n, int H, int W, gcv_stream s);
 
+/* Row N4: the crop + resize of face_rec (model/pred_func.py:79-85),
+ *   cv2.resize(frame[top:bottom, left:right], (224, 224), interpolation=cv2.INTER_AREA),
+ * for n faces in one launch.  frames: (nframes,H,W,3) uint8 RGB on the device; boxes5: int32 device array of n rows
+ * (frame index, top, right, bottom, left) — face_recognition's (top, right, bottom, left) order behind the index of the
+ * frame the face was found in; out: (n,size,size,3) uint8.  The reference's RGB<->BGR swaps around the resize cancel.
+ * A row outside its frame produces zeros (and reads nothing).  Face DETECTION (dlib) and video decode (decord) stay
+ * third-party CPU code on the caller's side. */
+int gcv_face_crop_resize(const void* frames_u8_nhwc, int nframes, int H, int W, const int* boxes5, int n,
+                         void* out_u8_nhwc, int size, gcv_stream s);
+
 /* pred_vid's reduction (model/pred_func.py:120,125): mean2[c] = mean_r sigmoid(logits[r][c]). */
 int gcv_vote(const float* logits, int rows, float* mean2, gcv_stream stream);
 

@@ -214,3 +214,79 @@ def test_committed_huggingface_fixture_is_what_the_script_produces(tmp_path):
     assert set(new) == set(old)
     for k in old:
         assert np.array_equal(new[k], old[k]), k
+
+
+# ----------------------------------------------------------------------------- row N4: cv2.INTER_AREA restatement
+# (parity unpinned against OpenCV itself — cv2 is not installed and the reference holds no fixture; these pin the
+# restatement to the definition of area resampling and to an independent implementation where one exists)
+def _sep(Wy, img, Wx):
+    """(Wy . img . Wx^T) per channel, in float64"""
+    return np.einsum("yh,hxc->yxc", Wy, np.einsum("hwc,xw->hxc", img.astype(np.float64), Wx))
+
+
+def _area_weights(s, d):
+    scale = s / d
+    W = np.zeros((d, s))
+    for dx in range(d):
+        a, b = dx * scale, min((dx + 1) * scale, s)
+        for sx in range(int(np.floor(a)), min(int(np.ceil(b)), s)):
+            W[dx, sx] = max(0.0, min(b, sx + 1) - max(a, sx))
+        W[dx] /= W[dx].sum()
+    return W
+
+
+@pytest.mark.parametrize("h,w", [(300, 310), (225, 500), (233, 224), (511, 397)])
+def test_cv_area_general_shrink_is_the_rounded_exact_area_mean(h, w):
+    from oracle import cv_area
+    src = np.random.default_rng(h * 1000 + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    out = cv_area.resize_area_u8(src)
+    exact = _sep(_area_weights(h, 224), src, _area_weights(w, 224))
+    assert np.abs(out - exact).max() <= 0.5 + 1e-3          # fp32 running sums: a tie may round either way
+
+
+@pytest.mark.parametrize("fy,fx", [(2, 2), (3, 3), (2, 3), (4, 1), (1, 1)])
+def test_cv_area_whole_factors_are_block_means_and_match_pillow_box(fy, fx):
+    from oracle import cv_area
+    src = np.random.default_rng(fy * 10 + fx).integers(0, 256, (224 * fy, 224 * fx, 3), dtype=np.uint8)
+    out = cv_area.resize_area_u8(src)
+    mean = src.reshape(224, fy, 224, fx, 3).astype(np.float64).mean(axis=(1, 3))
+    assert np.abs(out - mean).max() <= 0.5
+    if fy == fx == 1:
+        assert np.array_equal(out, src)
+    PIL = pytest.importorskip("PIL.Image")                  # an independent area-averaging resampler
+    box = np.asarray(PIL.fromarray(src).resize((224, 224), PIL.BOX))
+    assert np.abs(out.astype(int) - box.astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("h,w", [(100, 120), (150, 400), (400, 90), (1, 1), (223, 225)])
+def test_cv_area_growing_dimension_is_area_mode_bilinear(h, w):
+    """as soon as a dimension grows OpenCV interpolates between the two source pixels a destination cell overlaps, with
+    the overlap fractions as weights: the integer H / V passes against the same weights applied in floating point"""
+    from oracle import cv_area
+    src = np.random.default_rng(h * 7 + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    out = cv_area.resize_area_u8(src)
+
+    def weights(s, d):                                      # the fp32 overlap fractions, before the 11-bit rounding
+        ofs, coef, _ = cv_area._linear_tab(s, d, 1.0 / (d / s), d / s)
+        W = np.zeros((d, s))
+        for i in range(d):
+            W[i, ofs[i]] += coef[i][0] / cv_area.COEF_SCALE
+            if coef[i][1]:
+                W[i, ofs[i] + 1] += coef[i][1] / cv_area.COEF_SCALE
+        assert np.allclose(W.sum(1), 1.0, atol=1e-3) and (W >= 0).all()
+        return W
+    want = _sep(weights(h, 224), src, weights(w, 224))
+    assert np.abs(out - want).max() <= 1.0                  # 11-bit coefficients, truncating shifts
+    flat = cv_area.resize_area_u8(np.full((h, w, 3), 137, dtype=np.uint8))
+    assert np.all(flat == 137)
+
+
+def test_face_crop_needs_the_gpu_and_never_falls_back():
+    from genconvit_amd import _lib
+    from genconvit_amd.model import pred_func
+    if torch.cuda.is_available():
+        pytest.skip("CPU-only check")
+    frames = np.zeros((2, 64, 64, 3), dtype=np.uint8)
+    with pytest.raises(_lib.GenConViTHipError):
+        pred_func.face_rec(frames, locate=lambda fr: [(0, 4, 40, 40, 4)])
+    assert pred_func.face_rec(frames, locate=lambda fr: []) == ([], 0)       # reference :92

@@ -508,3 +508,53 @@ def test_in_place_weight_edits_and_oversize_batches(sd_ed):
     xb = synth.make_frames(4, name="edit").cuda().repeat(130, 1, 1, 1)      # 520 frames
     big = m(xb)
     assert big.shape == (520, 2) and (big[:4] - big[516:]).abs().max().item() <= 1e-6
+
+
+# ----------------------------------------------------------------------------- row N4: face crop + INTER_AREA resize
+def _boxes_all_regimes(nf, H, W):
+    """(frame, top, right, bottom, left) rows covering every branch of cv::resize(INTER_AREA) and the frame borders"""
+    return [
+        (0, 0, 448, 448, 0),                 # 2x2 whole factor: (a+b+c+d+2)>>2
+        (1, 10, 672 + 5, 672 + 10, 5),       # 3x3 whole factor: cvRound(sum / 9)
+        (2, 0, 448, 672, 0),                 # 3 (y) x 2 (x)
+        (0, 100, 324, 324, 100),             # scale 1: copy
+        (1, 33, 47 + 310, 33 + 300, 47),     # general shrink, both axes
+        (2, 200, 1000, 200 + 511, 603),      # general shrink, factor > 2 on y
+        (3, H - 233, W, H, W - 225),         # barely shrinking, touching the bottom-right corner
+        (0, 50, 170, 150, 50),               # both axes grow (100 x 120)
+        (1, 5, 405, 155, 5),                 # y grows, x shrinks -> bilinear path for both
+        (2, 300, 390, 700, 300),             # x grows, y shrinks
+        (3, 7, 8, 8, 7),                     # a single pixel
+        (3, 0, 223, 225, 0),                 # 225 x 223: one axis either side of 224
+        (nf - 1, 0, W, H, 0),                # the whole frame
+    ]
+
+
+def test_face_crop_resize_is_bit_equal_to_the_inter_area_restatement():
+    from oracle import cv_area
+    nf, H, W = 4, 720, 1280
+    rng = np.random.default_rng(5)
+    frames = rng.integers(0, 256, (nf, H, W, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    frames[3] = np.stack([(yy * 3 + xx) % 256, (xx * 2) % 256, (yy * xx // 97) % 256], -1).astype(np.uint8)   # smooth: ties
+    boxes = _boxes_all_regimes(nf, H, W)
+    got = _lib.face_crop_resize(torch.as_tensor(frames).cuda(), boxes).cpu().numpy()
+    want = cv_area.face_crops(frames, boxes)
+    for i, b in enumerate(boxes):
+        diff = np.abs(got[i].astype(int) - want[i].astype(int))
+        assert diff.max() == 0, f"box {i} {b}: {int((diff > 0).sum())} pixels differ, max {diff.max()}"
+
+
+def test_face_rec_crops_on_the_device_and_keeps_the_reference_contract():
+    from oracle import cv_area
+    rng = np.random.default_rng(6)
+    frames = rng.integers(0, 256, (3, 360, 640, 3), dtype=np.uint8)
+    found = [(0, 20, 300, 280, 40), (0, 100, 500, 200, 400), (2, 0, 640, 360, 0), (2, 5, 50, 50, 5)]   # > len(frames)
+    faces, count = pred_func.face_rec(frames, locate=lambda fr: list(found))
+    assert count == 3 and isinstance(faces, np.ndarray) and faces.shape == (3, 224, 224, 3) and faces.dtype == np.uint8
+    assert np.array_equal(faces, cv_area.face_crops(frames, found[:3]))        # reference :78: at most len(frames) faces
+    assert pred_func.face_rec(frames, locate=lambda fr: []) == ([], 0)
+    with pytest.raises(_lib.GenConViTHipError):
+        _lib.face_crop_resize(torch.as_tensor(frames).cuda(), [(0, 10, 700, 100, 10)])          # right edge outside the frame
+    x = pred_func.preprocess_frame(faces)                                        # the next stage of df_face (:139-141)
+    assert x.shape == (3, 3, 224, 224) and x.is_cuda
