@@ -946,6 +946,125 @@ __global__ void __launch_bounds__(256) conv3_first_kernel(const T* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------ K1/K9 first conv on the matrix pipe (16-bit storage)
+// 16 output channels x 27 taps is one v_mfma_f32_16x16x32 per 16 pixels (K = ci*9 + ky*3 + kx, padded to 32 with zero
+// weights): D[channel][pixel], a lane ends up with 4 consecutive channels of one pixel.  A workgroup stages the input
+// rows of an 8-row band of one frame in LDS (16-byte pieces, 8-element zero aprons left and right, zero rows outside the
+// frame); a lane gathers its 8 patch values with ds_read_u16 from 8 per-lane base addresses (they differ by lane
+// group, i.e. by which 8 of the 32 k it feeds) plus compile-time column offsets.
+//   POOL  (ED layer 1: conv s1 + ReLU + maxpool 2): the 16 pixels of an MFMA are a 2 x 8 block laid out so that a pool
+//         window is a lane quad (two DPP max); four MFMAs = 2 x 32 conv pixels = 16 pooled pixels x 16 channels = 512
+//         contiguous output bytes, and quad lane r stores the window of MFMA r: 8 bytes per lane, fully coalesced.
+//   !POOL (VAE layer 1: conv s2 + folded BN + LeakyReLU): the 16 pixels are 16 consecutive output columns.
+template <typename T> struct Mfma16;
+template <> struct Mfma16<half_t> {
+  __device__ static __forceinline__ f32x4 run(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mfma16<bf16_t> {
+  __device__ static __forceinline__ f32x4 run(const u32x4& a, const u32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+constexpr int kConv3MaxW = 224;
+
+template <typename T, bool POOL>
+__global__ void __launch_bounds__(256) conv3_first_mfma_kernel(const T* __restrict__ x, int64_t sb, int64_t sc, int64_t sy,
+                                                               const float* __restrict__ wp, const float* __restrict__ bias,
+                                                               T* __restrict__ out, int nimg, int H, int W, int act) {
+  static_assert(sizeof(T) == 2, "matrix-pipe first conv is built for 16-bit storage");
+  constexpr int RWS = POOL ? 10 : 9;                 // staged input rows of an 8-row band (one apron row above, one below)
+  constexpr int MPI = POOL ? 4 : 1;                  // MFMAs per work item
+  __shared__ __attribute__((aligned(16))) T sIn[3 * RWS * (kConv3MaxW + 16)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pitch = W + 16;
+  const int bands = H >> 3;
+  const int img = blockIdx.x / bands, band = blockIdx.x - img * bands;
+  const int row0 = 8 * band - 1;
+  const int Ho = H >> 1, Wo = W >> 1;
+  {   // ---- stage the band: (3 * RWS) rows of (W / 8 + 2) 16-byte pieces
+    const int ppr = (W >> 3) + 2;
+    const T* xi = x + (int64_t)img * sb;
+    for (int e = tid; e < 3 * RWS * ppr; e += 256) {
+      const int rr = e / ppr, pc = e - rr * ppr;
+      const int ci = rr / RWS, r = rr - ci * RWS;
+      const int iy = row0 + r;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (pc >= 1 && pc <= (W >> 3) && iy >= 0 && iy < H)
+        v = *reinterpret_cast<const u32x4*>(xi + (int64_t)ci * sc + (int64_t)iy * sy + 8 * (pc - 1));
+      *reinterpret_cast<u32x4*>(sIn + rr * pitch + 8 * pc) = v;
+    }
+  }
+  const int g = lane >> 4, j = lane & 15;
+  // weights: lane (g, channel j) holds k = 8g .. 8g+7 of that channel;  wp is [27][16] with k = (ky*3 + kx)*3 + ci
+  u32x4 wa;
+  int off[8];
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    uint32_t pk = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = 8 * g + i + h;
+      const int ci = k / 9, ky = (k - 9 * ci) / 3, kx = k - 9 * ci - 3 * ky;
+      const float wv = k < 27 ? wp[((ky * 3 + kx) * 3 + ci) * 16 + j] : 0.0f;
+      pk |= bits16<T>(wv) << (16 * h);
+      off[i + h] = k < 27 ? ((ci * RWS + ky) * pitch + kx) : 0;        // elements
+    }
+    wa[i >> 1] = pk;
+  }
+  const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 4 * g);
+  const int px = POOL ? (((j >> 1) & 1) * pitch + 2 * (j >> 2) + (j & 1) + 7) : (2 * j + 7);
+  const T* ap[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ap[i] = sIn + px + off[i];
+  __syncthreads();
+
+  const int ncg = W >> 5;
+  for (int it = wave; it < 4 * ncg; it += 4) {
+    const int rr = it / ncg, cg = it - rr * ncg;
+    const int ioff = 2 * rr * pitch + 32 * cg;
+    f32x4 acc[MPI];
+#pragma unroll
+    for (int m = 0; m < MPI; ++m) {
+      uint32_t v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const unsigned short*>(ap[i] + ioff + 8 * m);
+      u32x4 pb = {v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+      if (g == 3) { pb[1] &= 0xffffu; pb[2] = 0u; pb[3] = 0u; }        // k = 27 .. 31 do not exist
+      acc[m] = Mfma16<T>::run(wa, pb, b4);
+    }
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    if constexpr (POOL) {
+      f32x4 sel = acc[0];
+#pragma unroll
+      for (int m = 0; m < MPI; ++m) {
+        f32x4 pm;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float v = acc[m][c];
+          v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)));
+          v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true)));
+          pm[c] = v;
+        }
+        if (m == 0) sel = pm;
+        else if ((j & 3) == m) sel = pm;
+      }
+      t4 o4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o4[c] = from_f<T>(apply_act(sel[c], act));
+      const int yo = 4 * band + rr, xo = 16 * cg + 4 * (j & 3) + (j >> 2);
+      *reinterpret_cast<t4*>(out + (((int64_t)img * Ho + yo) * Wo + xo) * 16 + 4 * g) = o4;
+    } else {
+      t4 o4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o4[c] = from_f<T>(apply_act(acc[0][c], act));
+      const int yo = 4 * band + rr, xo = 16 * cg + j;
+      *reinterpret_cast<t4*>(out + (((int64_t)img * Ho + yo) * Wo + xo) * 16 + 4 * g) = o4;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ K2/K12 last ConvTranspose2d 16 -> 3
 // x NHWC (nimg,H,W,16) -> out NHWC (nimg,2H,2W,3); wp: [16][2][2][3] fp32 (ci,dy,dx,co).
 template <typename T>

@@ -117,6 +117,22 @@ int launch_conv3_first(const T* x, int64_t sb, int64_t sc, int64_t sy, int64_t s
                        T* out, int nimg, int H, int W, bool pool, int act, hipStream_t s) {
   GCV_REQUIRE(H % 2 == 0 && W % 2 == 0 && nimg > 0, "conv3_first: even H, W");
   const int64_t total = (int64_t)nimg * (H / 2) * (W / 2);
+  if constexpr (sizeof(T) == 2) {
+    // matrix-pipe variant: NCHW frames up to 224 wide whose rows are 16-byte pieces (GCV_CONV3_VALU=1: A/B switch)
+    static const bool valu = std::getenv("GCV_CONV3_VALU") != nullptr;
+    const bool ok = sx == 1 && W % 32 == 0 && W <= kConv3MaxW && H % 8 == 0 && ((sb | sc | sy) & 7) == 0 &&
+                    (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0 &&
+                    (reinterpret_cast<uintptr_t>(bias) & 15u) == 0;
+    if (ok && !valu) {
+      const dim3 g2((unsigned)(nimg * (H / 8)));
+      if (pool)
+        hipLaunchKernelGGL((conv3_first_mfma_kernel<T, true>), g2, dim3(256), 0, s, x, sb, sc, sy, wp, bias, out, nimg, H, W, act);
+      else
+        hipLaunchKernelGGL((conv3_first_mfma_kernel<T, false>), g2, dim3(256), 0, s, x, sb, sc, sy, wp, bias, out, nimg, H, W, act);
+      GCV_CHECK_HIP(hipGetLastError());
+      return 0;
+    }
+  }
   const dim3 grid((unsigned)cdiv64(total, 256));
   if (pool)
     hipLaunchKernelGGL((conv3_first_kernel<T, true>), grid, dim3(256), 0, s, x, sb, sc, sy, sx, wp, bias, out, nimg, H,

@@ -237,11 +237,12 @@ def test_layernorm_rows(dt, C):
 # ----------------------------------------------------------------------------- AE / VAE small kernels
 @pytest.mark.parametrize("dt", ALL)
 @pytest.mark.parametrize("pool", [True, False])
-def test_first_conv_3_to_16(dt, pool):
+@pytest.mark.parametrize("H", [32, 224, 20])          # 20: not a multiple of 8 -> the VALU kernel for every dtype
+def test_first_conv_3_to_16(dt, pool, H):
     dtype = DTYPES[dt]
-    n, H = 2, 32
+    n = 2
     x = q(rnd((n, 3, H, H), 1, 2.0), dtype)
-    w = rnd((16, 3, 3, 3), 2, 0.3)
+    w = q(rnd((16, 3, 3, 3), 2, 0.3), dtype)          # 16-bit storage runs on the matrix pipe: 16-bit weights
     b = rnd((16,), 3, 0.1)
     if pool:
         want = F.max_pool2d(F.relu(F.conv2d(x, w, b, padding=1)), 2)
