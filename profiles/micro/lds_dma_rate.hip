@@ -74,6 +74,10 @@ int main() {
     run<128, 3, 320>(1, Kb);     // whole lines, 3 x 40 KB, one workgroup per CU
     run<64, 3, 320>(2, Kb);
     run<64, 2, 320>(2, Kb);
+    run<64, 2, 320>(3, Kb);      // today's K = 384 configuration: three workgroups per CU
+    run<64, 4, 320>(1, Kb);      // ONE workgroup per CU (a persistent kernel): how deep must the ring be?
+    run<64, 6, 320>(1, Kb);
+    run<64, 8, 320>(1, Kb);
   }
   return 0;
 }
