@@ -13,7 +13,8 @@ def short(n):
 rows = list(csv.DictReader(open(sys.argv[1])))
 g = [r for r in rows if r['Kernel_Name'].startswith('_ZN3gcv') and 'pack_mu' not in r['Kernel_Name']]
 g.sort(key=lambda r: int(r['Start_Timestamp']))
-starts = [i for i, r in enumerate(g) if 'conv3_first_kernel' in r['Kernel_Name'] and 'Lb1' in r['Kernel_Name']]
+# a step starts with the ED encoder's first conv (POOL = true: 'Lb1'), VALU or matrix-pipe variant
+starts = [i for i, r in enumerate(g) if 'conv3_first_' in r['Kernel_Name'] and 'Lb1' in r['Kernel_Name']]
 last = g[starts[-1]:] if starts else g
 tot = 0.0
 agg = OrderedDict()

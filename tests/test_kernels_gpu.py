@@ -54,6 +54,9 @@ def assert_close(got, want, atol, what=""):
     (8, 1000, 768, 1),      # 32x128 tiles
     (130, 192, 1536, 0),    # downsample-conv shape class, long K
     (256, 96, 48, 3),       # K shorter than one 16-bit K tile
+    (9000, 384, 384, 2),    # pw1 at K = 384 on the LDS-DMA kernel: 142 tiles + an M tail, GELU
+    (8200, 192, 384, 0),    # ... one N tile, no activation
+    (70000, 1536, 384, 2),  # ... the stage-2 shape class at full N: several rounds of workgroups
 ])
 def test_gemm_bias_act(dt, M, N, K, act):
     dtype = DTYPES[dt]
