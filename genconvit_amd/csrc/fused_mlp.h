@@ -123,9 +123,12 @@ __global__ void __launch_bounds__(NW * 64, 2) fused_mlp_kernel(const MlpArgs a) 
     unsigned char* s1 = smem + buf * BUF;
     unsigned char* s2 = s1 + HC * ROW1;
     constexpr int RP1 = C * 2 / 16, RP2 = HC * 2 / 16;    // pieces per row
+    int t = tid;
+    if (C == 192) asm volatile("" : "+v"(t));             // recompute the LDS addresses here: hoisted out of the chunk loop
+                                                          // they were ten more live registers, spilled and reloaded per chunk
 #pragma unroll
     for (int i = 0; i < PH; ++i) {
-      const int idx = tid + (part * PH + i) * NT;
+      const int idx = t + (part * PH + i) * NT;
       if (idx < P1) {
         const int row = idx / RP1, c = idx - row * RP1;
         *(u32x4*)(s1 + row * ROW1 + c * 16) = stage_reg[i];
