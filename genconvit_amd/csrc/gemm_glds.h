@@ -78,7 +78,9 @@ __global__ void __launch_bounds__(256, 2) gemm_glds_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the DMA's LDS base (M0) and the tile offsets
+                                                                  // stay in SGPRs instead of a v_readfirstlane per DMA
   const int lr = lane & 31, lh = lane >> 5;
   const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 96;
 
