@@ -150,7 +150,7 @@ def test_conv_transpose_2x2(dt, n, H, cin, cout, act):
 
 # ----------------------------------------------------------------------------- ConvNeXt pieces
 @pytest.mark.parametrize("dt", ALL)
-@pytest.mark.parametrize("layout,res", [("nchw", 224), ("nhwc", 112), ("nchw", 32)])
+@pytest.mark.parametrize("layout,res", [("nchw", 224), ("nhwc", 112), ("nchw", 32), ("nchw", 20), ("nhwc", 20)])   # 20: a 25-token tail tile
 def test_stem_conv4x4_layernorm(dt, layout, res):
     dtype = DTYPES[dt]
     n = 2
