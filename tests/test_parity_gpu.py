@@ -558,3 +558,21 @@ def test_face_rec_crops_on_the_device_and_keeps_the_reference_contract():
         _lib.face_crop_resize(torch.as_tensor(frames).cuda(), [(0, 10, 700, 100, 10)])          # right edge outside the frame
     x = pred_func.preprocess_frame(faces)                                        # the next stage of df_face (:139-141)
     assert x.shape == (3, 3, 224, 224) and x.is_cuda
+
+
+def test_face_crop_resize_random_boxes_are_bit_equal():
+    """fuzz: 64 random boxes (sizes from 2 px to the whole frame, any aspect ratio) against the restatement"""
+    from oracle import cv_area
+    nf, H, W = 3, 480, 640
+    rng = np.random.default_rng(11)
+    frames = rng.integers(0, 256, (nf, H, W, 3), dtype=np.uint8)
+    boxes = []
+    for _ in range(64):
+        h = int(rng.integers(2, H + 1)) if rng.random() < 0.7 else int(rng.choice([112, 224, 448]))
+        w = int(rng.integers(2, W + 1)) if rng.random() < 0.7 else int(rng.choice([112, 224, 448]))
+        top, left = int(rng.integers(0, H - h + 1)), int(rng.integers(0, W - w + 1))
+        boxes.append((int(rng.integers(0, nf)), top, left + w, top + h, left))
+    got = _lib.face_crop_resize(torch.as_tensor(frames).cuda(), boxes).cpu().numpy()
+    want = cv_area.face_crops(frames, boxes)
+    bad = [(i, boxes[i]) for i in range(len(boxes)) if not np.array_equal(got[i], want[i])]
+    assert not bad, f"{len(bad)} boxes differ, first: {bad[0]}"
