@@ -16,9 +16,11 @@ What follows restates OpenCV 4.x `modules/imgproc/src/resize.cpp` as published, 
                                                     `fx = (dx + 1) - (sx + 1) * inv_scale`, 11-bit fixed point,
                                                     `HResizeLinear` / `VResizeLinear` integer arithmetic
 
-It is cross-checked (tests/test_oracle.py) against Pillow's BOX filter — an independent area-averaging resampler — to
-within 1 LSB on shrinking sizes, and against exact block means on whole factors.  Bit-equality with a given OpenCV
-build (IPP / OpenCL / HAL overrides differ between builds) is NOT claimed.
+It is tied (tests/test_oracle.py) to the definition — at most half an LSB from the exact area mean (float64 brute force)
+on shrinking sizes, exact block means on whole factors, the integer passes of the growing branch against the same weights
+in floating point — and to Pillow's BOX filter, an independent area-averaging resampler, within 1 LSB on whole factors
+(on fractional factors Pillow's BOX counts whole source pixels only, a different function).  Bit-equality with a given
+OpenCV build (IPP / OpenCL / HAL overrides differ between builds) is NOT claimed.
 """
 import math
 
