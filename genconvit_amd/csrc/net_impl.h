@@ -154,9 +154,42 @@ template <typename T> struct NetImpl : NetBase {
   // the C = 384 ring kernel (fused_mlp_ring.h) is correct but measures 309 us against 216 us for pw1 + pw2 at 256
   // images (one wave per SIMD cannot hide its LDS / MFMA latencies): opt-in for experiments only
   bool use_fused_mlp384 = std::getenv("GCV_FUSED_MLP384") != nullptr;
+  // vae_forward runs backbone(x) — which depends on nothing but the input — on a side stream while the encoder / mu GEMM /
+  // decoder chain (small, latency-bound launches) runs on the caller's stream; GCV_VAE_SPLIT=0 is the A/B switch
+  bool vae_split = [] { const char* e = std::getenv("GCV_VAE_SPLIT"); return e ? std::atoi(e) != 0 : true; }();
+  hipStream_t vae_side = nullptr;                      // (one per handle; the ED and the VAE network are separate handles)
+  hipEvent_t vae_fork = nullptr, vae_join = nullptr;
+  // the caller's stream waits for the side stream before the head reads its half of `feat` — and on every early return,
+  // so that whatever was enqueued is ordered before the caller's next work
+  struct Join {
+    hipStream_t s = nullptr; hipEvent_t ev = nullptr;
+    void arm(hipStream_t s_, hipEvent_t ev_) { s = s_; ev = ev_; }
+    void now() { if (ev) { (void)hipStreamWaitEvent(s, ev, 0); ev = nullptr; } }
+    ~Join() { now(); }
+  };
+  // run one backbone pass on the side stream, forked from `s` here
+  int side_pass(const CnxW<T>& w, const Seg<T>* seg, hipStream_t s, Join& join) {
+    if (!arena.dry) {
+      if (!vae_side) {
+        GCV_CHECK_HIP(hipStreamCreateWithFlags(&vae_side, hipStreamNonBlocking));
+        GCV_CHECK_HIP(hipEventCreateWithFlags(&vae_fork, hipEventDisableTiming));
+        GCV_CHECK_HIP(hipEventCreateWithFlags(&vae_join, hipEventDisableTiming));
+      }
+      GCV_CHECK_HIP(hipEventRecord(vae_fork, s));
+      GCV_CHECK_HIP(hipStreamWaitEvent(vae_side, vae_fork, 0));
+      cur = vae_side;
+    }
+    const int rc = run_convnext(w, seg, 1, true);
+    cur = s;
+    if (!arena.dry && hipEventRecord(vae_join, vae_side) == hipSuccess) join.arm(s, vae_join);
+    return rc;
+  }
 
   ~NetImpl() override {
     if (arena.base) (void)hipFree(arena.base);
+    if (vae_side) (void)hipStreamDestroy(vae_side);
+    if (vae_fork) (void)hipEventDestroy(vae_fork);
+    if (vae_join) (void)hipEventDestroy(vae_join);
   }
 
   size_t workspace_bytes() const override { return arena.cap; }
@@ -476,7 +509,9 @@ template <typename T> struct NetImpl : NetBase {
   }
 
   // ------------------------------------------------------------ ConvNeXt-T over token segments
-  int run_convnext(const CnxW<T>& w, const Seg<T>* segs, int nseg) {
+  // keep = true leaves the token buffers allocated (the caller releases its own mark): two passes of one forward that run
+  // on different streams must not share them
+  int run_convnext(const CnxW<T>& w, const Seg<T>* segs, int nseg, bool keep = false) {
     int h[4], wd[4];
     int64_t m[4], moff[4], M = 0;
     int ntot = 0;
@@ -578,7 +613,7 @@ template <typename T> struct NetImpl : NetBase {
       GCV_TRY(gemm("cnx.head_fc", g, A_PLAIN, EPI_BIAS_ACT));
       no += segs[s].n;
     }
-    arena.release(mk);
+    if (!keep) arena.release(mk);
     return 0;
   }
 
@@ -658,8 +693,9 @@ template <typename T> struct NetImpl : NetBase {
     GCV_TRY(run("ed.dec5_convT_relu", 2.0 * B * 112 * 112 * 16 * 12,
                 sizeof(T) * (double)B * (16 * 112 * 112 + 3 * 224 * 224),
                 [&] { return launch_convt2_small<T>(d4, ed.dec5_w, ed.dec5_b, rec, B, 112, 112, ACT_RELU, cur); }));
-    // both backbone passes share weights and shape -> one 2B-image token stream.
-    // cat order (genconvit_ed.py:85): [backbone(recon), backbone(orig)], activation GELU (:75)
+    // both backbone passes share weights and shape -> one 2B-image token stream (running backbone(orig) on a side stream
+    // under the encoder / decoder chain instead, as the VAE does, measured 8.69 vs 8.25 ms per step: the merged launches
+    // are worth more than the overlap).  cat order (genconvit_ed.py:85): [backbone(recon), backbone(orig)], GELU (:75)
     Seg<T> segs[2];
     segs[0] = Seg<T>{rec, (int64_t)224 * 224 * 3, 1, 224 * 3, 3, B, 224, 224, feat, 2000, ACT_GELU};
     segs[1] = Seg<T>{x, (int64_t)3 * 224 * 224, 224 * 224, 224, 1, B, 224, 224, feat + 1000, 2000, ACT_GELU};
@@ -697,6 +733,14 @@ template <typename T> struct NetImpl : NetBase {
     T* feat = arena.get<T>((int64_t)B * 2000);
     float* msepart = arena.get<float>((int64_t)B * 196);
     if (!arena.dry && arena.overflow) { set_error("workspace arena too small"); return -6; }
+
+    // cat order (genconvit_vae.py:113): [backbone(x @224), backbone(x_hat @112)], activation ReLU (:104)
+    Seg<T> segs[2];
+    segs[0] = Seg<T>{x, (int64_t)3 * 224 * 224, 224 * 224, 224, 1, B, 224, 224, feat, 2000, ACT_RELU};
+    segs[1] = Seg<T>{xhat, (int64_t)112 * 112 * 3, 1, 112 * 3, 3, B, 112, 112, feat + 1000, 2000, ACT_RELU};
+    const bool split = vae_split && !prof.enabled;       // (profiled steps stay on one stream: serial per-kernel times)
+    Join join;
+    if (split) GCV_TRY(side_pass(bb_vae, &segs[0], s, join));
 
     GCV_TRY(run("vae.enc1_conv3s2_bn_leaky", 2.0 * B * 112 * 112 * 16 * 27,
                 sizeof(T) * (double)B * (3 * 224 * 224 + 16 * 112 * 112), [&] {
@@ -748,11 +792,9 @@ template <typename T> struct NetImpl : NetBase {
     GCV_TRY(run("vae.dec4_convT_leaky", 2.0 * B * 56 * 56 * 16 * 12,
                 sizeof(T) * (double)B * (16 * 56 * 56 + 3 * 112 * 112),
                 [&] { return launch_convt2_small<T>(d3, vae.dec4_w, vae.dec4_b, xhat, B, 56, 56, ACT_LEAKY, cur); }));
-    // cat order (genconvit_vae.py:113): [backbone(x @224), backbone(x_hat @112)], activation ReLU (:104)
-    Seg<T> segs[2];
-    segs[0] = Seg<T>{x, (int64_t)3 * 224 * 224, 224 * 224, 224, 1, B, 224, 224, feat, 2000, ACT_RELU};
-    segs[1] = Seg<T>{xhat, (int64_t)112 * 112 * 3, 1, 112 * 3, 3, B, 112, 112, feat + 1000, 2000, ACT_RELU};
-    GCV_TRY(run_convnext(bb_vae, segs, 2));
+    if (split) { GCV_TRY(run_convnext(bb_vae, &segs[1], 1, true)); }
+    else { GCV_TRY(run_convnext(bb_vae, segs, 2)); }
+    join.now();
     GCV_TRY(run_head(vae.head, feat, B, ACT_RELU, logits));
     if (recon224 || mse) {
       GCV_TRY(run("vae.resize_mse", 30.0 * B * 224 * 224, sizeof(T) * (double)B * (3 * 112 * 112 + 6 * 224 * 224), [&] {
