@@ -74,7 +74,11 @@ int gcv_ed_forward(gcv_handle* h, const void* x_nchw, int batch, float* logits, 
  *   recon224 : nullable, (B,3,224,224) in the handle dtype = transforms.Resize((224,224))(x_hat) (:116)
  *   mse      : nullable, (B) fp32 per-frame mean((recon224 - x)^2); its mean is the reference's
  *              nn.MSELoss()(recons, images) (train/train_vae.py:24,76)
- *   kl       : nullable, (1) fp32 = Encoder.kl (model/genconvit_vae.py:58) */
+ *   kl       : nullable, (1) fp32 = Encoder.kl (model/genconvit_vae.py:58)
+ * backbone(x) (:111) depends on nothing but the input: it is enqueued on a side stream owned by the handle, forked
+ * from `stream` at the call and joined back into it by an event before the head, while the encoder / decoder chain and
+ * backbone(x_hat) run on `stream` itself.  For the caller nothing changes: all work is ordered after what `stream` held
+ * at the call and before what it is given next; no synchronisation.  (GCV_VAE_SPLIT=0 keeps everything on `stream`.) */
 int gcv_vae_forward(gcv_handle* h, const void* x_nchw, const float* eps, int batch, float* logits,
                     void* recon224, float* mse, float* kl, gcv_stream stream);
 
