@@ -13,6 +13,7 @@
 
 #include "fused_mlp.h"
 #include "gemm.h"
+#include "mlp_pair.h"
 #include "kernels.h"
 #include "net.h"
 
@@ -114,6 +115,32 @@ static int to_map(const gcv_tensor_desc* w, int n, TensorMap& m) {
     m[w[i].name] = TensorRef{(const float*)w[i].data, w[i].numel, w[i].on_device != 0};
   }
   return 0;
+}
+
+// ConvNeXt MLP (16-bit only): W1 is given as (4C, C) T, W2 as plain (C, 4C) fp32 on the device; both are packed here.
+// C = 96 / 192: the fused kernels; C = 384: the pw1 / pw2 kernel pair with its fragment-major hidden tensor.
+template <typename T>
+static int k_mlp_dispatch(int C, const void* x, const void* w1, const float* b1, const float* w2_f32, const float* b2,
+                          const float* gamma, const void* resid, void* out, int M, hipStream_t s) {
+  struct DevBuf {                                  // freed on every exit path (after the stream has drained)
+    void* p = nullptr;
+    hipStream_t s;
+    explicit DevBuf(hipStream_t st) : s(st) {}
+    ~DevBuf() { if (p) { (void)hipStreamSynchronize(s); (void)hipFree(p); } }
+  };
+  DevBuf w2c(s), w1f(s), hid(s);
+  GCV_CHECK_HIP(hipMalloc(&w2c.p, (size_t)4 * C * C * 2));
+  if (mlp_pair_supported(C)) {
+    GCV_CHECK_HIP(hipMalloc(&w1f.p, (size_t)4 * C * C * 2));
+    GCV_CHECK_HIP(hipMalloc(&hid.p, mlp_pair_hidden_bytes(M, C)));
+    GCV_TRY((launch_pack_w1_frag<T, T>((const T*)w1, (T*)w1f.p, C, s)));
+    GCV_TRY((launch_pack_w2_frag<T, float>(w2_f32, (T*)w2c.p, C, s)));
+    MlpPairArgs a{x, w1f.p, b1, w2c.p, b2, gamma, resid, out, hid.p, M};
+    return launch_mlp_pair<T>(a, C, s);
+  }
+  MlpArgs a{x, w1, b1, w2c.p, b2, gamma, resid, out, M};
+  GCV_TRY(launch_pack_w2_chunks<T>(w2_f32, (T*)w2c.p, C, s));
+  return launch_fused_mlp<T>(a, C, s);
 }
 
 extern "C" {
@@ -420,24 +447,11 @@ int gcv_face_crop_resize(const void* frames_u8_nhwc, int nframes, int H, int W, 
                                  size, (hipStream_t)s);
 }
 
-// fused ConvNeXt MLP (16-bit only): W2 is given as plain (C,4C) fp32 on the device and packed here
 int gcv_k_fused_mlp(int dtype, int C, const void* x, const void* w1, const float* b1, const float* w2_f32,
                     const float* b2, const float* gamma, const void* resid, void* out, int M, gcv_stream s) {
-  GCV_REQUIRE(dtype == GCV_F16 || dtype == GCV_BF16, "fused MLP is built for 16-bit storage");
-  void* w2c = nullptr;
-  GCV_CHECK_HIP(hipMalloc(&w2c, (size_t)4 * C * C * 2));
-  int rc;
-  MlpArgs a{x, w1, b1, w2c, b2, gamma, resid, out, M};
-  if (dtype == GCV_F16) {
-    rc = launch_pack_w2_chunks<half_t>(w2_f32, (half_t*)w2c, C, (hipStream_t)s);
-    if (!rc) rc = launch_fused_mlp<half_t>(a, C, (hipStream_t)s);
-  } else {
-    rc = launch_pack_w2_chunks<bf16_t>(w2_f32, (bf16_t*)w2c, C, (hipStream_t)s);
-    if (!rc) rc = launch_fused_mlp<bf16_t>(a, C, (hipStream_t)s);
-  }
-  (void)hipStreamSynchronize((hipStream_t)s);
-  (void)hipFree(w2c);
-  return rc;
+  GCV_REQUIRE(dtype == GCV_F16 || dtype == GCV_BF16, "the MLP kernels are built for 16-bit storage");
+  if (dtype == GCV_F16) return k_mlp_dispatch<half_t>(C, x, w1, b1, w2_f32, b2, gamma, resid, out, M, (hipStream_t)s);
+  return k_mlp_dispatch<bf16_t>(C, x, w1, b1, w2_f32, b2, gamma, resid, out, M, (hipStream_t)s);
 }
 
 }  // extern "C"

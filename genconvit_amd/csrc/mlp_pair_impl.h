@@ -1,0 +1,91 @@
+// launchers + weight packers of the C = 384 MLP kernel pair (included by mlp_pair_{f16,bf16}.hip)
+#pragma once
+#include "mlp_pair.h"
+
+namespace gcv {
+
+template <typename T, typename S> int launch_pack_w1_frag(const S* w1, T* out, int C, hipStream_t s) {
+  GCV_REQUIRE(C % 32 == 0, "pack_w1_frag: C must be a multiple of 32");
+  const int64_t total = (int64_t)4 * C * C;
+  hipLaunchKernelGGL((pack_w1_frag_kernel<T, S>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, w1, out, C);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+template <typename T, typename S> int launch_pack_w2_frag(const S* w2, T* out, int C, hipStream_t s) {
+  GCV_REQUIRE(C % 32 == 0, "pack_w2_frag: C must be a multiple of 32");
+  const int64_t total = (int64_t)4 * C * C;
+  hipLaunchKernelGGL((pack_w2_frag_kernel<T, S>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, w2, out, C);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// Work split of pw1: a workgroup costs its x tile (~3 chunk times) plus its hidden chunks; workgroups beyond the CU
+// count queue behind the first round (one workgroup per CU: the ring takes the whole LDS)
+static inline int xs_pw1_pick_split(int ntile, int nkc) {
+  int best = 1;
+  long best_cost = -1;
+  for (int ns = 1; ns <= 8; ++ns) {
+    if (nkc % ns) continue;
+    const long rounds = ((long)ntile * ns + 255) / 256;
+    const long cost = rounds * (nkc / ns + 3);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ns; }
+  }
+  return best;
+}
+
+static inline int mlp_pair_check(const MlpPairArgs& a, int C) {
+  GCV_REQUIRE(a.M > 0 && a.X && a.W1f && a.W2f && a.b1 && a.b2 && a.gamma && a.resid && a.out && a.hidden,
+              "MLP pair: null argument");
+  GCV_REQUIRE(mlp_pair_supported(C), "MLP pair is built for C = 384");
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  GCV_REQUIRE(al(a.X) && al(a.W1f) && al(a.W2f) && al(a.b1) && al(a.resid) && al(a.out) && al(a.hidden),
+              "MLP pair: operands must be 16-byte aligned");
+  GCV_REQUIRE((int64_t)cdiv(a.M, 32) * (4 * C / 32) * 2048 < ((int64_t)1 << 31),
+              "MLP pair: hidden tensor exceeds 32-bit buffer offsets");
+  return 0;
+}
+
+template <typename T, int C> static int launch_xs_pw1_c(const MlpPairArgs& a, hipStream_t s) {
+  constexpr int NKC = 4 * C / 32;
+  constexpr int NW = 8, D = 6;
+  constexpr int SMEM = XsPw1Smem<C, NW, D>::bytes;
+  GCV_ENSURE_LDS((xs_pw1_kernel<T, C, NW, D>), SMEM);
+  const int ntile = cdiv(a.M, 32 * NW);
+  const int ns = xs_pw1_pick_split(ntile, NKC);
+  hipLaunchKernelGGL((xs_pw1_kernel<T, C, NW, D>), dim3(ntile, ns), dim3(NW * 64), SMEM, s, a, NKC / ns);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T, int C> static int launch_pw2f_c(const MlpPairArgs& a, hipStream_t s) {
+  const int ntm = cdiv(a.M, 256);
+  // full-width tiles halve the operand bytes per FLOP but need >= ~0.7 x 256 of them to keep the chip busy
+  if (ntm >= 180) {
+    constexpr int BN = C, D = 3;
+    constexpr int SMEM = Pw2fSmem<C, BN, D>::bytes;
+    GCV_ENSURE_LDS((pw2f_kernel<T, C, BN, D>), SMEM);
+    hipLaunchKernelGGL((pw2f_kernel<T, C, BN, D>), dim3(ntm), dim3(512), SMEM, s, a);
+  } else {
+    constexpr int BN = 192, D = 5;
+    constexpr int SMEM = Pw2fSmem<C, BN, D>::bytes;
+    GCV_ENSURE_LDS((pw2f_kernel<T, C, BN, D>), SMEM);
+    hipLaunchKernelGGL((pw2f_kernel<T, C, BN, D>), dim3(ntm * (C / BN)), dim3(512), SMEM, s, a);
+  }
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T> int launch_xs_pw1(const MlpPairArgs& a, int C, hipStream_t s) {
+  GCV_TRY(mlp_pair_check(a, C));
+  return launch_xs_pw1_c<T, 384>(a, s);
+}
+template <typename T> int launch_pw2f(const MlpPairArgs& a, int C, hipStream_t s) {
+  GCV_TRY(mlp_pair_check(a, C));
+  return launch_pw2f_c<T, 384>(a, s);
+}
+template <typename T> int launch_mlp_pair(const MlpPairArgs& a, int C, hipStream_t s) {
+  GCV_TRY(launch_xs_pw1<T>(a, C, s));
+  return launch_pw2f<T>(a, C, s);
+}
+
+}  // namespace gcv

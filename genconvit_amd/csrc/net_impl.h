@@ -13,6 +13,7 @@
 #include <cstring>
 
 #include "fused_mlp.h"
+#include "mlp_pair.h"
 #include "gemm.h"
 #include "kernels.h"
 #include "net.h"
@@ -93,7 +94,8 @@ __global__ void __launch_bounds__(256) pack_mu_kernel(const float* __restrict__ 
 template <typename T> struct CnxBlockW {
   float *dw_w, *dw_b, *ln_w, *ln_b, *fc1_b, *fc2_b, *gamma;
   T *fc1_w, *fc2_w;
-  T* fc2_wc;       // 16-bit, C <= 384: W2 packed for the fused MLP kernels (else null)
+  T* fc2_wc;       // 16-bit, C <= 192: W2 packed for the fused MLP kernels (else null)
+  T *fc1_wf, *fc2_wf;   // 16-bit, C = 384: W1 / W2 in MFMA-fragment order for the pw1 / pw2 kernel pair (else null)
 };
 template <typename T> struct CnxW {
   float *stem_w, *stem_b, *stem_lnw, *stem_lnb;
@@ -154,6 +156,7 @@ template <typename T> struct NetImpl : NetBase {
   // the C = 384 ring kernel (fused_mlp_ring.h) is correct but measures 309 us against 216 us for pw1 + pw2 at 256
   // images (one wave per SIMD cannot hide its LDS / MFMA latencies): opt-in for experiments only
   bool use_fused_mlp384 = std::getenv("GCV_FUSED_MLP384") != nullptr;
+  bool use_mlp_pair = std::getenv("GCV_NO_MLP_PAIR") == nullptr;     // C = 384: pw1 / pw2 kernel pair (mlp_pair.h)
   // vae_forward runs backbone(x) — which depends on nothing but the input — on a side stream while the encoder / mu GEMM /
   // decoder chain (small, latency-bound launches) runs on the caller's stream; GCV_VAE_SPLIT=0 is the A/B switch
   bool vae_split = [] { const char* e = std::getenv("GCV_VAE_SPLIT"); return e ? std::atoi(e) != 0 : true; }();
@@ -352,7 +355,16 @@ template <typename T> struct NetImpl : NetBase {
         GCV_TRY(up_f32(w, b + "mlp.fc1.bias", 4 * C, st, k.fc1_b));
         GCV_TRY(up_cast(w, b + "mlp.fc2.weight", (int64_t)4 * C * C, st, k.fc2_w));
         k.fc2_wc = nullptr;
+        k.fc1_wf = k.fc2_wf = nullptr;
         if constexpr (sizeof(T) == 2) {
+          if (mlp_pair_supported(C) && use_mlp_pair) {
+            k.fc1_wf = (T*)st.raw((size_t)4 * C * C * sizeof(T));
+            k.fc2_wf = (T*)st.raw((size_t)4 * C * C * sizeof(T));
+            if (!k.fc1_wf || !k.fc2_wf) { set_error("hipMalloc failed for the fragment-major fc1 / fc2"); return -5; }
+            GCV_TRY((launch_pack_w1_frag<T, T>(k.fc1_w, k.fc1_wf, C, nullptr)));
+            GCV_TRY((launch_pack_w2_frag<T, T>(k.fc2_w, k.fc2_wf, C, nullptr)));
+            GCV_CHECK_HIP(hipDeviceSynchronize());
+          }
           if (C <= 192 || (C == 384 && use_fused_mlp384)) {   // stages with a fused MLP kernel in use
             std::vector<float> v;
             GCV_TRY(fetch(w, b + "mlp.fc2.weight", (int64_t)4 * C * C, v));
@@ -587,6 +599,16 @@ template <typename T> struct NetImpl : NetBase {
             MlpArgs ma{Y, k.fc1_w, k.fc1_b, k.fc2_wc, k.fc2_b, k.gamma, X, X, (int)M};
             GCV_TRY(run("cnx.fused_mlp", 16.0 * M * C * (double)C, 3.0 * sizeof(T) * (double)M * C + 16.0 * C * C,
                         [&] { return launch_fused_mlp<T>(ma, C, cur); }));
+            continue;
+          }
+        }
+        if constexpr (sizeof(T) == 2) {
+          if (k.fc1_wf && k.fc2_wf) {
+            MlpPairArgs pa{Y, k.fc1_wf, k.fc1_b, k.fc2_wf, k.fc2_b, k.gamma, X, X, Hd, (int)M};
+            GCV_TRY(run("cnx.pw1_gelu", 8.0 * M * C * (double)C, sizeof(T) * (5.0 * M * C + 4.0 * C * C),
+                        [&] { return launch_xs_pw1<T>(pa, C, cur); }));
+            GCV_TRY(run("cnx.pw2_scale_res", 8.0 * M * C * (double)C, sizeof(T) * (6.0 * M * C + 4.0 * C * C),
+                        [&] { return launch_pw2f<T>(pa, C, cur); }));
             continue;
           }
         }
