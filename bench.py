@@ -70,7 +70,7 @@ def log(msg):
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def measured_traffic(family: str, net: str, batch: int, dtype: str):
+def measured_traffic(family: str, net: str, batch: int, dtype: str, launches_per_step: int):
     """HBM bytes per launch of a kernel family from a committed rocprofv3 PMC run of THIS configuration
     (profiles/r*_traffic*.json, written by profiles/pmc_bench_traffic.sh: FETCH_SIZE x2 + WRITE_SIZE in separate
     passes, with the net / batch / dtype it was recorded on).  PMC counters cannot be collected from inside the
@@ -83,7 +83,13 @@ def measured_traffic(family: str, net: str, batch: int, dtype: str):
             c = d.get("config", {})
             if (c.get("net"), c.get("batch"), c.get("dtype")) != (net, batch, dtype):
                 continue
-            return round(d["families"][family]["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
+            fam = d["families"][family]
+            # the PMC file must have been recorded on the same launch structure: its dispatch count is steps x this
+            # run's launches per step, or it describes other kernels (a stale file after the kernels changed, or a
+            # family classification that swept in other GEMMs) and is refused
+            if fam.get("dispatches") != fam.get("steps", 0) * launches_per_step:
+                continue
+            return round(fam["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
         except Exception:
             continue
     return None, None
@@ -263,7 +269,8 @@ def main():
             else:
                 achieved = d["bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
                 peak, unit = PEAK["hbm"], "GB/s"
-            traffic, traffic_src = measured_traffic(tkey, a.net, a.batch, a.dtype) if tkey else (None, None)
+            lps = d["launches"] // max(a.profile_steps, 1)
+            traffic, traffic_src = measured_traffic(tkey, a.net, a.batch, a.dtype, lps) if tkey else (None, None)
             return {"kernel": name, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
@@ -321,6 +328,14 @@ def main():
                 "frames_per_s_genconvit_plus_swin": round(a.batch / (t_sw + dt / a.steps), 1),
                 "algorithmic_gflop_per_frame": 8.98}
 
+    # evidence for the multi-GPU path: how the logit all-gather travelled, how many ranks RCCL itself counts, and which
+    # device every rank ran on (gathered over the process group; one rank: just this device)
+    comm = None
+    if dist_on:
+        names = [None] * world
+        torch.distributed.all_gather_object(names, f"{torch.cuda.get_device_name(device)} (cuda:{local_rank})")
+        info = gdist.comm_info()
+        comm = {"backend": "nccl (RCCL)", "allgather_path": info["path"], "rccl_ranks": info["ranks"], "devices": names}
     if rank == 0:
         fps = n_global * a.steps / dt
         line = {
@@ -334,6 +349,9 @@ def main():
                        "net": a.net, "frames_per_gpu": a.batch, "global_batch": n_global,
                        "parallelism": f"frame-shard x{world}", "algorithmic_gflop_per_frame": GFLOP_PER_FRAME[a.net]},
             "roofline": roof, "roofline_families": roof_families, "cpu_baseline": cpu,
+            "rccl_ranks": comm["rccl_ranks"] if comm else 0,
+            "comm": comm if comm else {"backend": None, "allgather_path": "none (one process, no collective)", "rccl_ranks": 0,
+                                       "devices": [f"{torch.cuda.get_device_name(device)} (cuda:{local_rank})"]},
         }
         if swin is not None:
             line["swin_embedder"] = swin

@@ -52,6 +52,8 @@ SIGNATURES = {
     "gcv_ed_forward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "gcv_vae_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gcv_genconvit_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "gcv_comm_available": (c_int, []),
+    "gcv_comm_count": (c_int, [c_void_p]),
     "gcv_comm_unique_id": (c_int, [c_void_p]),
     "gcv_comm_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_void_p, c_int]),
     "gcv_comm_destroy": (None, [c_void_p]),
@@ -329,6 +331,16 @@ class Comm:
         self._c = c_void_p()
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)
         check(self.lib.gcv_comm_create(ctypes.byref(self._c), self.world, self.rank, buf, self.device_index), "gcv_comm_create")
+
+    @staticmethod
+    def available() -> bool:
+        """RCCL and its entry points can be bound in this process (dlopen + dlsym; starts nothing)."""
+        Comm._share_torch_rccl()
+        return bool(load().gcv_comm_available())
+
+    def count(self) -> int:
+        """Ranks in the communicator as RCCL itself reports them (ncclCommCount)."""
+        return int(self.lib.gcv_comm_count(self._c))
 
     @staticmethod
     def unique_id() -> bytes:

@@ -14,6 +14,7 @@
 #include "fused_mlp.h"
 #include "gemm.h"
 #include "mlp_pair.h"
+#include "xs_mlp.h"
 #include "kernels.h"
 #include "net.h"
 
@@ -67,6 +68,7 @@ struct Rccl {
   int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
+  int (*CommCount)(void*, int*) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   std::string err;
 };
@@ -87,6 +89,7 @@ Rccl& rccl() {
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
     r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+    r.CommCount = (decltype(r.CommCount))dlsym(r.lib, "ncclCommCount");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
     if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) r.err = "librccl.so lacks the nccl* entry points";
   });
@@ -138,6 +141,13 @@ static int k_mlp_dispatch(int C, const void* x, const void* w1, const float* b1,
     MlpPairArgs a{x, w1f.p, b1, w2c.p, b2, gamma, resid, out, hid.p, M};
     return launch_mlp_pair<T>(a, C, s);
   }
+  static const bool legacy = exp_env("GCV_MLP_LEGACY") != nullptr;   // A/B: the round-2 fused kernels
+  if (xs_mlp_default(C) && !legacy) {
+    GCV_CHECK_HIP(hipMalloc(&w1f.p, xs_mlp_packed_elems(C) * sizeof(T)));
+    GCV_TRY((launch_pack_xs_mlp<T, float>((const T*)w1, w2_f32, (T*)w1f.p, C, s)));
+    XsMlpArgs xa{x, w1f.p, b1, b2, gamma, resid, out, M};
+    return launch_xs_mlp<T>(xa, C, s);
+  }
   MlpArgs a{x, w1, b1, w2c.p, b2, gamma, resid, out, M};
   GCV_TRY(launch_pack_w2_chunks<T>(w2_f32, (T*)w2c.p, C, s));
   return launch_fused_mlp<T>(a, C, s);
@@ -146,6 +156,15 @@ static int k_mlp_dispatch(int C, const void* x, const void* w1, const float* b1,
 extern "C" {
 
 const char* gcv_last_error(void) { return get_error(); }
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev); else prev = -1;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 
 int gcv_create(gcv_handle** out, int device, int dtype, int max_batch) {
   GCV_REQUIRE(out != nullptr, "null handle pointer");
@@ -168,6 +187,7 @@ int gcv_create(gcv_handle** out, int device, int dtype, int max_batch) {
   net->device = device;
   net->dtype = dtype;
   net->max_batch = max_batch;
+  DeviceGuard g(device);                                 // init() makes `device` current: restore the caller's on return
   const int rc = net->init();
   if (rc) { delete net; return rc; }
   *out = new gcv_handle{net, {}};
@@ -189,6 +209,7 @@ int gcv_load_ed(gcv_handle* h, const gcv_tensor_desc* w, int n) {
   GCV_REQUIRE(h, "null handle");
   TensorMap m;
   if (int rc = to_map(w, n, m)) return rc;
+  DeviceGuard g(h->net->device);                         // the loaders make the handle's device current: restore the caller's
   return h->net->load_ed(m);
 }
 
@@ -196,6 +217,7 @@ int gcv_load_vae(gcv_handle* h, const gcv_tensor_desc* w, int n) {
   GCV_REQUIRE(h, "null handle");
   TensorMap m;
   if (int rc = to_map(w, n, m)) return rc;
+  DeviceGuard g(h->net->device);                         // the loaders make the handle's device current: restore the caller's
   return h->net->load_vae(m);
 }
 
@@ -203,18 +225,11 @@ int gcv_load_swin(gcv_handle* h, const gcv_tensor_desc* w, int n, const char* pr
   GCV_REQUIRE(h, "null handle");
   TensorMap m;
   if (int rc = to_map(w, n, m)) return rc;
+  DeviceGuard g(h->net->device);
   return h->net->load_swin(m, prefix ? prefix : "");
 }
 
 // the forwards make the handle's device current for their launches and restore the caller's afterwards
-struct DeviceGuard {
-  int prev = -1;
-  explicit DeviceGuard(int dev) {
-    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-    if (prev != dev) (void)hipSetDevice(dev); else prev = -1;
-  }
-  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
 
 int gcv_ed_forward(gcv_handle* h, const void* x_nchw, int batch, float* logits, gcv_stream stream) {
   GCV_REQUIRE(h, "null handle");
@@ -246,6 +261,19 @@ int gcv_genconvit_forward(gcv_handle* he, gcv_handle* hv, const void* x_nchw, co
     if (hipEventRecord(he->ev_join[i], he->side[i]) == hipSuccess) (void)hipStreamWaitEvent(s, he->ev_join[i], 0);
   }
   return rc;
+}
+
+int gcv_comm_available(void) {
+  Rccl& r = rccl();                       // dlopen + symbol lookup only: no bootstrap listener is started
+  if (!r.err.empty()) { set_error(r.err); return 0; }
+  return 1;
+}
+
+int gcv_comm_count(gcv_comm* c) {
+  if (!c) return 0;
+  int n = 0;
+  if (c->comm && rccl().CommCount && rccl().CommCount(c->comm, &n) == 0) return n;   // what RCCL itself says
+  return c->world;
 }
 
 int gcv_comm_unique_id(void* id128) {

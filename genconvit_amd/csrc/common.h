@@ -99,6 +99,18 @@ __device__ __forceinline__ float wave_max(float v) {
   return fmaxf(v, __shfl_xor(v, 32, 64));
 }
 
+// ---- A/B switches ---------------------------------------------------------
+// The shipped library reads two environment variables: GCV_VAE_SPLIT (schedule of gcv_vae_forward, net_impl.h) and
+// GCV_RCCL_PATH (api.hip).  Every other switch between a default kernel and a slower / older alternative exists only
+// in builds with -DGCV_EXPERIMENTS (profiles/build_variant.sh <name> "-DGCV_EXPERIMENTS" ...): exp_env() is the one
+// place they are read, and it is a constant in the product build, so the alternatives are dead code there.
+#ifdef GCV_EXPERIMENTS
+#include <cstdlib>
+static inline const char* exp_env(const char* name) { return std::getenv(name); }
+#else
+static inline const char* exp_env(const char*) { return nullptr; }
+#endif
+
 // ---- host side -------------------------------------------------------------
 void set_error(const std::string& msg);
 const char* get_error();

@@ -10,7 +10,7 @@
 namespace gcv {
 
 static inline int dw_env_int(const char* name, int dflt) {
-  const char* e = std::getenv(name);
+  const char* e = exp_env(name);
   return e ? std::atoi(e) : dflt;
 }
 

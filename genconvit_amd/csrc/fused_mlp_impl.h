@@ -4,7 +4,9 @@
 
 #include "fused_mlp.h"
 #include "fused_mlp_res.h"
-#include "fused_mlp_ring.h"
+#ifdef GCV_EXPERIMENTS
+#include "fused_mlp_ring.h"      // opt-in LDS-DMA ring MLP (C = 192 / 384): measured slower, kept for A/B runs only
+#endif
 
 namespace gcv {
 
@@ -25,13 +27,16 @@ __global__ void __launch_bounds__(256) pack_w2_chunks_kernel(const float* __rest
   out[i] = from_f<T>(w2[(int64_t)o * 4 * C + ch * HC + hid]);
 }
 
-// The LDS-DMA ring kernel (fused_mlp_ring.h) is the only fused kernel for C = 384; at C = 192 it is an experiment
-// (GCV_MLP_RING192=1: 288 us vs 279 us for the streaming kernel at 256 images — with two groups of prefetch the ring is
-// fill-latency bound: PMC shows 60 % of wave cycles in s_waitcnt / barrier).  The packed W2 layout follows the choice:
-// 32-wide hidden groups for the ring kernel, 96-wide chunks otherwise.
+// The LDS-DMA ring kernel (fused_mlp_ring.h, GCV_EXPERIMENTS builds only) wants W2 packed in 32-wide hidden groups, the
+// streaming kernel in 96-wide chunks; it is opt-in there (GCV_FUSED_MLP384=1 at C = 384, GCV_MLP_RING192=1 at C = 192).
 static inline bool mlp_use_ring(int C) {
-  static const bool ring192 = [] { const char* e = std::getenv("GCV_MLP_RING192"); return e ? std::atoi(e) != 0 : false; }();
+#ifdef GCV_EXPERIMENTS
+  static const bool ring192 = [] { const char* e = exp_env("GCV_MLP_RING192"); return e ? std::atoi(e) != 0 : false; }();
   return C == 384 || (C == 192 && ring192);
+#else
+  (void)C;
+  return false;
+#endif
 }
 static inline int mlp_chunk_width(int C) { return mlp_use_ring(C) ? 32 : kMlpHC; }
 
@@ -55,7 +60,7 @@ template <typename T, int C, int NW> static int launch_mlp_c(const MlpArgs& a, h
 template <typename T> int launch_fused_mlp_res(const MlpArgs& a, hipStream_t s) {
   constexpr int SMEM = MlpResSmem::bytes;
   GCV_ENSURE_LDS((fused_mlp_res_kernel<T>), SMEM);
-  static const int nw = [] { const char* e = std::getenv("GCV_MLP_RES_WAVES"); return e ? std::atoi(e) : 8; }();
+  static const int nw = [] { const char* e = exp_env("GCV_MLP_RES_WAVES"); return e ? std::atoi(e) : 8; }();
   const int wave_tiles = cdiv(a.M, 32);
   const int nwg = cdiv(wave_tiles, nw) < 256 ? cdiv(wave_tiles, nw) : 256;    // one persistent workgroup per CU
   hipLaunchKernelGGL((fused_mlp_res_kernel<T>), dim3(nwg), dim3(64 * nw), SMEM, s, a);
@@ -63,6 +68,7 @@ template <typename T> int launch_fused_mlp_res(const MlpArgs& a, hipStream_t s) 
   return 0;
 }
 
+#ifdef GCV_EXPERIMENTS
 template <typename T, int C> static int launch_mlp_ring_c(const MlpArgs& a, hipStream_t s) {
   constexpr int SMEM = MlpRingSmem<C>::bytes;
   GCV_ENSURE_LDS((fused_mlp_ring_kernel<T, C>), SMEM);
@@ -80,17 +86,21 @@ template <typename T> int launch_fused_mlp_ring(const MlpArgs& a, int C, hipStre
   return -3;
 }
 
+#endif
+
 template <typename T> int launch_fused_mlp(const MlpArgs& a, int C, hipStream_t s) {
   GCV_REQUIRE(a.M > 0 && a.X && a.W1 && a.W2c && a.b1 && a.b2 && a.gamma && a.resid && a.out, "fused MLP: null argument");
   // C=96: 4-wave workgroups (81 KB LDS -> two independent workgroups per CU overlap each other's
   // prologue / epilogue); C=192: the double-buffered chunks fill the LDS, one 8-wave workgroup per CU
   // C=96 with enough tokens to give every wave of the chip several tiles: weights resident in LDS, no barriers
-  static const int res_mode = [] { const char* e = std::getenv("GCV_MLP_RESIDENT"); return e ? std::atoi(e) : 1; }();
+  static const int res_mode = [] { const char* e = exp_env("GCV_MLP_RESIDENT"); return e ? std::atoi(e) : 1; }();
   if (C == 96 && res_mode && a.M >= 256 * 8 * 32) return launch_fused_mlp_res<T>(a, s);
   if (C == 96) return launch_mlp_c<T, 96, 4>(a, s);
+#ifdef GCV_EXPERIMENTS
   if (mlp_use_ring(C)) return launch_fused_mlp_ring<T>(a, C, s);
+#endif
   if (C == 192) return launch_mlp_c<T, 192, 8>(a, s);
-  set_error("fused MLP is built for C = 96, 192 and 384");
+  set_error("fused MLP kernels of this file: C = 96, 192");
   return -3;
 }
 

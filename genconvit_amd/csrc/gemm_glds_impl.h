@@ -16,13 +16,13 @@ template <typename T, int EPI, int ACT, int BKB> static int launch_glds_bkb(cons
 }
 
 template <typename T, int EPI, int ACT> static int launch_glds_cfg(const GemmArgs& g, hipStream_t s) {
-  static const bool line64 = std::getenv("GCV_GLDS_ROW64") != nullptr;    // A/B switch: force the 64-byte-row ring
+  static const bool line64 = exp_env("GCV_GLDS_ROW64") != nullptr;    // A/B switch: force the 64-byte-row ring
   if (g.K % 64 == 0 && g.K >= 512 && !line64) return launch_glds_bkb<T, EPI, ACT, 128>(g, s);   // (K = 384: 6 stages, the 4-deep ring wins)
   return launch_glds_bkb<T, EPI, ACT, 64>(g, s);
 }
 
 template <typename T> bool gemm_glds_applicable(const GemmArgs& g, int a_mode, int epi) {
-  static const bool disabled = std::getenv("GCV_NO_GLDS") != nullptr;     // A/B switch for profiling
+  static const bool disabled = exp_env("GCV_NO_GLDS") != nullptr;     // A/B switch for profiling
   if (disabled || sizeof(T) != 2 || a_mode != A_PLAIN) return false;
   if (!(epi == EPI_BIAS_ACT && (g.act == ACT_NONE || g.act == ACT_GELU)) && !(epi == EPI_RESID && g.act == ACT_NONE))
     return false;

@@ -68,8 +68,12 @@ template <typename T> int launch_gemm(const GemmArgs& g, int a_mode, int epi, hi
 #define C3(A) launch_cfg<T, 128, 96, 32, 96, B, A_PLAIN, EPI_BIAS_ACT, A>(g, s)
 #define C3S(A) launch_cfg<T, 128, 96, 32, 96, 64, A_PLAIN, EPI_BIAS_ACT, A>(g, s)
 #define C4(A) launch_cfg<T, 128, 128, 64, 64, B, A_PLAIN, EPI_BIAS_ACT, A>(g, s)
-    if (g.M <= 32) { GCV_ACT_SWITCH(C1) }
-    if (g.M <= 64) { GCV_ACT_SWITCH(C2) }
+    // small problems (the classifier heads: M = frames <= 256, N = 500 / 1000): with 128-row tiles they are 4-16
+    // workgroups on a 256-CU chip and take 20-50 us of pure latency; 32- / 64-row tiles spread the same work over 4x / 2x
+    // as many CUs
+    const int t128 = cdiv(g.M, 128) * cdiv(g.N, 128);
+    if (g.M <= 32 || t128 < 48) { GCV_ACT_SWITCH(C1) }
+    if (g.M <= 64 || t128 < 96) { GCV_ACT_SWITCH(C2) }
     if (g.N % 96 == 0) {
       if (short_k) { GCV_ACT_SWITCH(C3S) }
       GCV_ACT_SWITCH(C3)

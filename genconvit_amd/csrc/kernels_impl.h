@@ -16,7 +16,7 @@ int launch_stem_ln(const T* x, int64_t sb, int64_t sc, int64_t sy, int64_t sx, c
   GCV_REQUIRE((reinterpret_cast<uintptr_t>(wp) & 15u) == 0, "stem: packed weights must be 16-byte aligned");
   if constexpr (sizeof(T) == 2) {
     // matrix-pipe stem: the two frame layouts of the path with 8-byte aligned patch pieces (GCV_STEM_VALU=1: A/B switch)
-    static const bool valu = std::getenv("GCV_STEM_VALU") != nullptr;
+    static const bool valu = exp_env("GCV_STEM_VALU") != nullptr;
     const bool al = (reinterpret_cast<uintptr_t>(x) & 7u) == 0 && ((sb | sy) & 3) == 0 &&
                     (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
     const bool nchw4 = al && sx == 1 && (sc & 3) == 0, nhwc4 = al && sc == 1 && sx == 3;
@@ -55,7 +55,7 @@ int launch_dwconv7_ln(const T* x, const float* wdw, const float* bdw, const floa
   GCV_REQUIRE(nimg > 0 && H > 0 && W > 0, "dwconv: empty");
   // the rolling-strip kernel covers every ConvNeXt-T shape but the 3x3 map of the 112-px pass
   // (GCV_DWCONV_GENERIC=1: A/B switch, the generic tile kernel everywhere)
-  static const bool generic = std::getenv("GCV_DWCONV_GENERIC") != nullptr;
+  static const bool generic = exp_env("GCV_DWCONV_GENERIC") != nullptr;
   if (!generic && dwconv_roll_applicable<T>(H, W, C) &&
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) == 0)
     return launch_dwconv7_ln_roll<T>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, C, eps, s);
@@ -119,7 +119,7 @@ int launch_conv3_first(const T* x, int64_t sb, int64_t sc, int64_t sy, int64_t s
   const int64_t total = (int64_t)nimg * (H / 2) * (W / 2);
   if constexpr (sizeof(T) == 2) {
     // matrix-pipe variant: NCHW frames up to 224 wide whose rows are 16-byte pieces (GCV_CONV3_VALU=1: A/B switch)
-    static const bool valu = std::getenv("GCV_CONV3_VALU") != nullptr;
+    static const bool valu = exp_env("GCV_CONV3_VALU") != nullptr;
     const bool ok = sx == 1 && W % 32 == 0 && W <= kConv3MaxW && H % 8 == 0 && ((sb | sc | sy) & 7) == 0 &&
                     (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0 &&
                     (reinterpret_cast<uintptr_t>(bias) & 15u) == 0;
@@ -194,7 +194,7 @@ int launch_swin_window_attn(const T* qkv, const float* rpb, T* out, int nimg, in
   GCV_REQUIRE(shift == 0 || (shift == 3 && H > 7), "swin attention: shift is 0 or 3");
   const float scale = 0.17677669529663689f;   // 32^-0.5
   if constexpr (sizeof(T) == 2) {
-    static const bool valu_only = std::getenv("GCV_SWIN_ATTN_VALU") != nullptr;   // A/B switch
+    static const bool valu_only = exp_env("GCV_SWIN_ATTN_VALU") != nullptr;   // A/B switch
     if (!valu_only && (reinterpret_cast<uintptr_t>(qkv) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && C % 8 == 0) {
       hipLaunchKernelGGL((swin_window_attn_mfma_kernel<T>), dim3(nimg * (H / 7) * (W / 7), nH), dim3(64), 0, s, qkv, rpb,
                          out, H, W, C, nH, shift, scale);

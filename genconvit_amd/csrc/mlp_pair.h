@@ -81,11 +81,14 @@ template <int C, int NW, int D> struct XsPw1Smem {
 #ifndef GCV_XS_STAMPS
 #define GCV_XS_STAMPS 0    // diagnostic builds only: s_memtime stamps of workgroups 0..63 (wave 0) into a side buffer
 #endif
+#ifndef GCV_XS_STAMP_WAVE
+#define GCV_XS_STAMP_WAVE 0
+#endif
 #if GCV_XS_STAMPS
 __device__ unsigned long long gcv_xs_stamps[64 * 64];
 #define XS_STAMP(i)                                                                   \
   do {                                                                                \
-    if (blockIdx.x < 64 && blockIdx.y == 0 && threadIdx.x == 0) {                      \
+    if (blockIdx.x < 64 && blockIdx.y == 0 && threadIdx.x == 64 * GCV_XS_STAMP_WAVE) {  \
       unsigned long long _t;                                                          \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");       \
       gcv_xs_stamps[blockIdx.x * 64 + (i)] = _t;                                      \
@@ -184,13 +187,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) xs_pw1_kernel(const MlpPairAr
     for (int i = 0; i < PPW; ++i) issue_piece(i);
     issue_advance();
   };
-  // Inside a step the pieces are issued one at a time, at the head of a sub-block, and the two waves of a SIMD take
-  // turns (waves 0-3 before sub-blocks 0, 2, 4, waves 4-7 before 1, 3, 5): an LDS-DMA instruction holds its wave for
-  // 60-180 cycles (more when the eight waves of the workgroup queue theirs at the address unit together, as they did
-  // right behind the barrier: 300-400 cycles per step with the SIMD idle), and a wave stalled there costs nothing while
-  // its partner has MFMAs and vector work to issue.
-  static_assert(PPW <= 3, "one piece per pair of sub-blocks");
-  const int late = (wave >> 2) & 1;
+  // (Spreading a step's pieces over its sub-blocks, the two waves of a SIMD taking turns, was measured and is worse:
+  //  86 us against 80 us at 256 images.  An LDS-DMA instruction costs its SIMD the same issue time wherever it sits.)
   XS_STAMP(0);
 #pragma unroll
   for (int s = 0; s < D - 1; ++s) issue();
@@ -231,10 +229,16 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) xs_pw1_kernel(const MlpPairAr
       const t4 h4 = {from_f<T>(v[0]), from_f<T>(v[1]), from_f<T>(v[2]), from_f<T>(v[3])};
       pk[qq] = __builtin_bit_cast(uint2, h4);
     }
-    const auto sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
-    const auto sy = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
-    const u32x4 w = {sx[0], sy[0], sx[1], sy[1]};
-    if (!(GCV_XS_ABLATE & 4) || w[0] == 0x12345u)
+    u32x4 w;
+    if (!(GCV_XS_ABLATE & 32)) {
+      const auto sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+      const auto sy = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+      w = (u32x4){sx[0], sy[0], sx[1], sy[1]};
+    } else {
+      w = (u32x4){pk[0].x, pk[0].y, pk[1].x, pk[1].y};
+    }
+    if (GCV_XS_ABLATE & 64) asm volatile("" ::"v"(w));      // keeps the whole GELU alive without the store
+    else if (!(GCV_XS_ABLATE & 4) || w[0] == 0x12345u)
       __builtin_amdgcn_raw_buffer_store_b128(w, rsh, hbase + (unsigned)kc * 2048u + (unsigned)half * 1024u, 0, 0);
   };
 
@@ -256,9 +260,6 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) xs_pw1_kernel(const MlpPairAr
   auto sub_block = [&](f32x16& cur, f32x16& nxt, int kc, auto jc, auto gc) {
     constexpr int j = decltype(jc)::value;
     constexpr bool gelu_prev = decltype(gc)::value;
-    if (!(GCV_XS_ABLATE & 2) && (j & 1) == late && (j >> 1) < PPW) issue_piece(j >> 1);
-    if (j == 5) issue_advance();
-    __builtin_amdgcn_sched_barrier(0);
     u32x4 w0[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) w0[i] = wf[i];
@@ -280,6 +281,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) xs_pw1_kernel(const MlpPairAr
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (gelu_prev && (kc == 10 || kc == 11)) XS_STAMP(32 + 8 * (kc - 10) + j);
   };
   // One step: chunk `kc` lands, its 24 MFMAs go into `nxt` while the GELU of chunk kc-1 (in `cur`) runs in their shadow.
   // Wait count: the DMAs of chunk kc were issued D-1 steps ago; younger than them are the (D-2) * PPW DMAs of chunks
@@ -297,6 +299,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) xs_pw1_kernel(const MlpPairAr
     if (kc >= 8 && kc < 16) XS_STAMP(2 * kc);
     GCV_XS_WAIT(WAITN);
     if (kc >= 8 && kc < 16) XS_STAMP(2 * kc + 1);
+    if (!(GCV_XS_ABLATE & 2)) issue();
     sw = smem + slot_r * SLOT + lane * 16;
     slot_r = slot_r + 1 == D ? 0 : slot_r + 1;
     read_bias(nxt, kc);
@@ -311,6 +314,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) xs_pw1_kernel(const MlpPairAr
   GCV_XS_WAIT(WAITN);
 #pragma unroll
   for (int p = 0; p < KP; ++p) asm volatile("" : "+v"(xf[p]));   // no use of xf may move above the wait
+  issue();
   slot_r = 1;
   read_bias(accA, 0);
   read_frags(0);

@@ -14,6 +14,7 @@
 
 #include "fused_mlp.h"
 #include "mlp_pair.h"
+#include "xs_mlp.h"
 #include "gemm.h"
 #include "kernels.h"
 #include "net.h"
@@ -95,6 +96,7 @@ template <typename T> struct CnxBlockW {
   float *dw_w, *dw_b, *ln_w, *ln_b, *fc1_b, *fc2_b, *gamma;
   T *fc1_w, *fc2_w;
   T* fc2_wc;       // 16-bit, C <= 192: W2 packed for the fused MLP kernels (else null)
+  T* fc_wp;        // 16-bit, C <= 192: W1 | W2 records of the x-stationary fused MLP (xs_mlp.h) (else null)
   T *fc1_wf, *fc2_wf;   // 16-bit, C = 384: W1 / W2 in MFMA-fragment order for the pw1 / pw2 kernel pair (else null)
 };
 template <typename T> struct CnxW {
@@ -152,11 +154,11 @@ template <typename T> struct NetImpl : NetBase {
   bool has_ed = false, has_vae = false, has_swin = false;
   Arena arena;
   hipStream_t cur = nullptr;
-  bool use_fused_mlp = std::getenv("GCV_NO_FUSED_MLP") == nullptr;   // A/B switches for profiling
-  // the C = 384 ring kernel (fused_mlp_ring.h) is correct but measures 309 us against 216 us for pw1 + pw2 at 256
-  // images (one wave per SIMD cannot hide its LDS / MFMA latencies): opt-in for experiments only
-  bool use_fused_mlp384 = std::getenv("GCV_FUSED_MLP384") != nullptr;
-  bool use_mlp_pair = std::getenv("GCV_NO_MLP_PAIR") == nullptr;     // C = 384: pw1 / pw2 kernel pair (mlp_pair.h)
+  bool use_fused_mlp = exp_env("GCV_NO_FUSED_MLP") == nullptr;   // A/B switches for profiling
+  // (GCV_EXPERIMENTS builds only, see common.h exp_env: the round-2 kernels behind their old switches)
+  bool use_fused_mlp384 = exp_env("GCV_FUSED_MLP384") != nullptr;
+  bool use_mlp_pair = exp_env("GCV_NO_MLP_PAIR") == nullptr;     // C = 384: pw1 / pw2 kernel pair (mlp_pair.h)
+  bool use_xs_mlp = exp_env("GCV_MLP_LEGACY") == nullptr;        // C = 192: x-stationary fused MLP (xs_mlp.h)
   // vae_forward runs backbone(x) — which depends on nothing but the input — on a side stream while the encoder / mu GEMM /
   // decoder chain (small, latency-bound launches) runs on the caller's stream; GCV_VAE_SPLIT=0 is the A/B switch
   bool vae_split = [] { const char* e = std::getenv("GCV_VAE_SPLIT"); return e ? std::atoi(e) != 0 : true; }();
@@ -356,7 +358,14 @@ template <typename T> struct NetImpl : NetBase {
         GCV_TRY(up_cast(w, b + "mlp.fc2.weight", (int64_t)4 * C * C, st, k.fc2_w));
         k.fc2_wc = nullptr;
         k.fc1_wf = k.fc2_wf = nullptr;
+        k.fc_wp = nullptr;
         if constexpr (sizeof(T) == 2) {
+          if (xs_mlp_default(C) && use_xs_mlp) {
+            k.fc_wp = (T*)st.raw(xs_mlp_packed_elems(C) * sizeof(T));
+            if (!k.fc_wp) { set_error("hipMalloc failed for the packed fc1 | fc2 records"); return -5; }
+            GCV_TRY((launch_pack_xs_mlp<T, T>(k.fc1_w, k.fc2_w, k.fc_wp, C, nullptr)));
+            GCV_CHECK_HIP(hipDeviceSynchronize());
+          }
           if (mlp_pair_supported(C) && use_mlp_pair) {
             k.fc1_wf = (T*)st.raw((size_t)4 * C * C * sizeof(T));
             k.fc2_wf = (T*)st.raw((size_t)4 * C * C * sizeof(T));
@@ -365,7 +374,7 @@ template <typename T> struct NetImpl : NetBase {
             GCV_TRY((launch_pack_w2_frag<T, T>(k.fc2_w, k.fc2_wf, C, nullptr)));
             GCV_CHECK_HIP(hipDeviceSynchronize());
           }
-          if (C <= 192 || (C == 384 && use_fused_mlp384)) {   // stages with a fused MLP kernel in use
+          if ((C <= 192 && !k.fc_wp) || (C == 384 && use_fused_mlp384)) {   // stages with a round-2 fused MLP kernel in use
             std::vector<float> v;
             GCV_TRY(fetch(w, b + "mlp.fc2.weight", (int64_t)4 * C * C, v));
             struct DevBuf {                        // freed on every exit path
@@ -595,6 +604,12 @@ template <typename T> struct NetImpl : NetBase {
           s = e;
         }
         if constexpr (sizeof(T) == 2) {
+          if (k.fc_wp) {
+            XsMlpArgs xa{Y, k.fc_wp, k.fc1_b, k.fc2_b, k.gamma, X, X, (int)M};
+            GCV_TRY(run("cnx.fused_mlp", 16.0 * M * C * (double)C, 3.0 * sizeof(T) * (double)M * C + 16.0 * C * C,
+                        [&] { return launch_xs_mlp<T>(xa, C, cur); }));
+            continue;
+          }
           if (k.fc2_wc && use_fused_mlp && (C < 384 || use_fused_mlp384)) {
             MlpArgs ma{Y, k.fc1_w, k.fc1_b, k.fc2_wc, k.fc2_b, k.gamma, X, X, (int)M};
             GCV_TRY(run("cnx.fused_mlp", 16.0 * M * C * (double)C, 3.0 * sizeof(T) * (double)M * C + 16.0 * C * C,

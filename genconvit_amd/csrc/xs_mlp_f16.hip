@@ -1,0 +1,13 @@
+// x-stationary fused ConvNeXt MLP (C = 96 / 192) for storage dtype half_t
+#include "xs_mlp_impl.h"
+namespace gcv {
+template int launch_xs_mlp<half_t>(const XsMlpArgs&, int, hipStream_t);
+template int launch_pack_xs_mlp<half_t, half_t>(const half_t*, const half_t*, half_t*, int, hipStream_t);
+template int launch_pack_xs_mlp<half_t, float>(const half_t*, const float*, half_t*, int, hipStream_t);
+}
+
+#if GCV_XM_STAMPS
+extern "C" __attribute__((visibility("default"))) int gcv_debug_read_xm_stamps(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gcv::gcv_xm_stamps), sizeof(unsigned long long) * n);
+}
+#endif

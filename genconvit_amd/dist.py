@@ -28,21 +28,33 @@ def _c_comm(group, device):
         from . import _lib
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         # ncclCommInitRank blocks until every rank has joined: first make sure, over the torch group, that RCCL could be
-        # bound on ALL ranks (each draws a throw-away id as the probe); otherwise every rank keeps torch's all_gather
+        # bound on ALL ranks (gcv_comm_available: dlopen + symbol lookup, nothing is started); otherwise every rank keeps
+        # torch's all_gather.  Only rank 0 then draws the ncclUniqueId (each ncclGetUniqueId starts a bootstrap listener).
         try:
-            uid, ok = _lib.Comm.unique_id(), 1
-        except Exception as e:      # library / symbols missing on this rank
-            uid, ok = None, 0
-            print(f"[genconvit_amd.dist] rank {rank}: RCCL not bound through the C ABI ({e}); using torch.distributed", flush=True)
+            ok = 1 if _lib.Comm.available() else 0
+            why = _lib.last_error() if not ok else ""
+        except Exception as e:      # library missing on this rank
+            ok, why = 0, str(e)
+        if not ok:
+            print(f"[genconvit_amd.dist] rank {rank}: RCCL not bound through the C ABI ({why}); using torch.distributed", flush=True)
         flag = torch.tensor([ok], dtype=torch.int32, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         if int(flag.item()) == 0:
             _COMMS[key] = None
         else:
-            box = [uid if rank == 0 else None]
+            box = [_lib.Comm.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             _COMMS[key] = _lib.Comm(world, rank, box[0], device.index if device.index is not None else torch.cuda.current_device())
     return _COMMS[key]
+
+
+def comm_info(group=None):
+    """How the logit all-gather of ``group`` travels: {"path": "c_abi" | "torch", "ranks": ranks RCCL / the group reports}."""
+    key = id(group) if group is not None else 0
+    c = _COMMS.get(key)
+    if c is not None:
+        return {"path": "c_abi(gcv_allgather_logits -> ncclAllGather)", "ranks": c.count()}
+    return {"path": "torch.distributed.all_gather", "ranks": dist.get_world_size(group) if dist.is_initialized() else 1}
 
 
 def close_comms():

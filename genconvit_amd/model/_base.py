@@ -100,7 +100,9 @@ class HipModule(nn.Module):
         self._dirty = True
 
     def _weights_signature(self):
-        # in-place edits (p.mul_(), optimizer-style writes) bump ``_version``; re-assigned Parameters change identity
+        # in-place edits (p.mul_(), optimizer-style writes) bump ``_version``.  The parameter list is cached between packs,
+        # so a RE-ASSIGNED Parameter (module.fc.weight = nn.Parameter(...)) is not seen here: invalidate() is the contract
+        # for that (docstring above)
         ps = self._sig_params
         if ps is None:
             ps = self._sig_params = list(self.parameters()) + list(self.buffers())

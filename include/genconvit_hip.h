@@ -128,11 +128,16 @@ int gcv_vote_segments(const float* logits, int batch, int nets, const int* offse
  * device, model/pred_func.py:15).  The only exchange of the path is one all-gather of per-frame logits before the
  * vote.  RCCL is bound at run time (dlopen: $GCV_RCCL_PATH, an already loaded librccl, then
  * /opt/rocm/lib) so that the library shares the process's RCCL the way it shares its HIP runtime.
+ *   gcv_comm_available : 1 when RCCL and its entry points could be bound in this process (dlopen + dlsym only), else 0
+ *                        with the reason in gcv_last_error(): the cheap probe every rank runs before the collective
+ *   gcv_comm_count     : ranks in the communicator as RCCL reports them (ncclCommCount)
  *   gcv_comm_unique_id : rank 0 fills 128 bytes (ncclUniqueId); the caller ships them to every rank (any channel)
  *   gcv_comm_create    : collective over all `world` ranks (ncclCommInitRank) on `device`
  *   gcv_allgather_logits: all[r * n_local .. (r+1) * n_local) = rank r's `local` (n_local floats, equal on all
  *                        ranks: pad ragged shards), enqueued on `stream`; world = 1 is a device copy */
 typedef struct gcv_comm gcv_comm;
+int  gcv_comm_available(void);
+int  gcv_comm_count(gcv_comm* c);
 int  gcv_comm_unique_id(void* id128);
 int  gcv_comm_create(gcv_comm** c, int world, int rank, const void* id128, int device);
 void gcv_comm_destroy(gcv_comm* c);

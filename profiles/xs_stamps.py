@@ -27,3 +27,12 @@ print(f"start -> step 8   : {med(16, 0):9.0f}")
 for k in range(8, 16):
     nxt = med(2 * k + 2, 2 * k + 1) if k < 15 else float('nan')
     print(f"step {k:2d}: wait+barrier {med(2 * k + 1, 2 * k):7.0f}   body {nxt:7.0f}")
+for k in (10, 11):
+    base = 2 * k + 1
+    prev = base
+    line = []
+    for j in range(6):
+        i = 32 + 8 * (k - 10) + j
+        line.append(f"{med(i, prev):5.0f}")
+        prev = i
+    print(f"step {k}: sub-blocks after the barrier: " + " ".join(line))

@@ -51,6 +51,18 @@ def vae_model(dtype=torch.float32):
     return _CACHE[key]
 
 
+def fresh_vae(dtype, split, monkeypatch):
+    """A VAE model on a NEW handle created under GCV_VAE_SPLIT=<split>: the library reads the switch when a handle is
+    constructed (net_impl.h), so the two schedules of gcv_vae_forward — backbone(x) forked to a side stream, or one
+    merged two-segment pass on the caller's stream (what --no-concurrent, every profiled step and profiles/*serial*
+    run) — are both reachable from one test process."""
+    from tests.conftest import synthetic_sd
+    monkeypatch.setenv("GCV_VAE_SPLIT", "1" if split else "0")
+    m = GenConViTVAE(load_config(), init="empty")
+    m.load_state_dict(synthetic_sd("vae"))
+    return m.to("cuda").to(dtype).eval()
+
+
 # ----------------------------------------------------------------------------- fp32: the parity gate
 def test_ed_fp32_matches_reference_golden(golden, sd_ed):
     x = synth.make_frames(4)
@@ -239,6 +251,32 @@ def test_vae_16bit_delta_vs_fp32_oracle_and_same_dtype_restatement(dtype, golden
     err_same = (got - same).abs().max().item()
     print(f"\nVAE {dtype} B=4: |logits - fp32 reference golden| = {err:.3e}; vs same-dtype restatement {err_same:.3e}")
     assert err <= BOUND_16[dtype] and err_same <= BOUND_16[dtype]
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_vae_both_schedules_fp32_golden_and_bf16_batch32(split, golden, sd_vae, monkeypatch):
+    """Both schedules of gcv_vae_forward (see fresh_vae) against the reference golden at fp32 and, at configs[2]'s size,
+    against the fp32 oracle at bf16; the two schedules must also agree with each other bit for bit (same kernels, same
+    order per stream)."""
+    x = synth.make_frames(4)
+    eps = torch.from_numpy(golden["vae_eps"])
+    m = fresh_vae(torch.float32, split, monkeypatch)
+    logits, recon = m(x.cuda(), eps=eps.cuda(), want_recon=True, want_mse=True, want_kl=True)
+    err_gold = np.abs(logits.cpu().numpy() - golden["vae_logits"]).max()
+    assert err_gold <= FP32_TOL
+    assert np.abs(slice64(recon) - golden["vae_recon_slice"]).max() <= 1e-3
+    assert np.abs(m.mse.cpu().numpy() - golden["vae_mse"]).max() <= 1e-3 * golden["vae_mse"].max()
+    ref = vae_model()(x.cuda(), eps=eps.cuda(), want_recon=False)[0]          # the cached model: default schedule
+    assert torch.equal(logits, ref), "the split and the merged VAE schedule must give identical logits"
+    del m
+    xb = synth.make_frames(32, name="cfg3")
+    eb = synth.make_eps(32, name="cfg3")
+    mb = fresh_vae(torch.bfloat16, split, monkeypatch)
+    got = mb(xb.cuda(), eps=eb.cuda(), want_recon=False)[0].cpu()
+    want = cpu_ref.vae_forward(sd_vae, xb, eb)[0]
+    err = (got - want).abs().max().item()
+    print(f"\nVAE split={split}: fp32 B=4 vs golden {err_gold:.3e}; bf16 B=32 vs fp32 oracle {err:.3e}")
+    assert got.shape == (32, 2) and torch.isfinite(got).all() and err <= 5e-2
 
 
 def test_full_size_config3_vae_batch32_bf16(sd_vae):
