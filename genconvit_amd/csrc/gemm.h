@@ -162,9 +162,14 @@ typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 struct GeluH16 {                       // polynomial state of NP pairs of values between the three phases
   template <int NP> struct State { h16x2 t[NP], p[NP]; };
   static __device__ __forceinline__ h16x2 k2(float c) { return (h16x2){(_Float16)c, (_Float16)c}; }
-  static constexpr float kC[11] = {2.749713404e-02f, -1.330395067e-01f, 2.465923971e-01f, -1.472158060e-01f,
-                                   -2.029683018e-01f, 4.347813707e-01f, -2.049071560e-01f, -1.763150062e-01f,
-                                   1.763803063e-01f, 2.178248281e-02f, -4.258673483e-02f};
+  // the polynomial carries -h/2 (every coefficient times -0.5: exact in fp16), so that the last step is
+  // y = fma(p, 2, max(x, 0)) with the fp16 -> fp32 widening of p inside the instruction (v_fma_mix_f32; a multiplier
+  // of -1 is folded into a subtraction first and then costs a separate v_cvt_f32_f16 per value)
+  static constexpr float kScale = 2.0f;
+  static constexpr float kC[11] = {-0.5f * 2.749713404e-02f, 0.5f * 1.330395067e-01f, -0.5f * 2.465923971e-01f,
+                                   0.5f * 1.472158060e-01f, 0.5f * 2.029683018e-01f, -0.5f * 4.347813707e-01f,
+                                   0.5f * 2.049071560e-01f, 0.5f * 1.763150062e-01f, -0.5f * 1.763803063e-01f,
+                                   -0.5f * 2.178248281e-02f, 0.5f * 4.258673483e-02f};
   // phase A: a = min(|x|, 4.5) -> fp16, t = 2a/4.5 - 1, Horner levels 10 .. LAST (inclusive)
   template <int NP, int LAST> static __device__ __forceinline__ void begin(const float* x, State<NP>& st) {
 #pragma unroll
@@ -194,8 +199,8 @@ struct GeluH16 {                       // polynomial state of NP pairs of values
       // where fmaxf canonicalises its operand first; the fp16 -> fp32 widening of h rides on the fma (v_fma_mix_f32)
       const float r0 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, x[2 * c]), 0));
       const float r1 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, x[2 * c + 1]), 0));
-      y[2 * c] = __builtin_fmaf((float)st.p[c][0], -1.0f, r0);
-      y[2 * c + 1] = __builtin_fmaf((float)st.p[c][1], -1.0f, r1);
+      y[2 * c] = __builtin_fmaf((float)st.p[c][0], kScale, r0);
+      y[2 * c + 1] = __builtin_fmaf((float)st.p[c][1], kScale, r1);
     }
   }
 };

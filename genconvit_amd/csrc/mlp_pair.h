@@ -78,6 +78,9 @@ template <int C, int NW, int D> struct XsPw1Smem {
 #ifndef GCV_XS_ABLATE
 #define GCV_XS_ABLATE 0    // diagnostic builds only: 1 = no GELU arithmetic, 2 = no DMA after the prologue, 4 = no stores,
 #endif                     //                         8 = no MFMA, 16 = no fragment reads after the first
+#ifndef GCV_XS_SGB
+#define GCV_XS_SGB 1      // 1 = 1 MFMA : 1 LDS read : n vector instructions (product); 0 / 2 / 3 diagnostics, see sub_block
+#endif
 #ifndef GCV_XS_STAMPS
 #define GCV_XS_STAMPS 0    // diagnostic builds only: s_memtime stamps of workgroups 0..63 (wave 0) into a side buffer
 #endif
@@ -272,6 +275,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) xs_pw1_kernel(const MlpPairAr
       if (j % 3 == 0 && !(GCV_XS_ABLATE & 1)) gelu_a(cur, j / 3);
       if (j % 3 == 1 && !(GCV_XS_ABLATE & 1)) gelu_b();
       if (j % 3 == 2) gelu_c(cur, j / 3, kc - 1);
+#if GCV_XS_SGB == 1
       if (j == 0) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);    // vector work first: the first fragments are
 #pragma unroll                                                          // still on their way from LDS
       for (int i = 0; i < 4; ++i) {
@@ -279,6 +283,15 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) xs_pw1_kernel(const MlpPairAr
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, j == 0 ? 6 : 9, 0);
       }
+#elif GCV_XS_SGB == 2                                                   // diagnostic: the four MFMAs, then the vector work
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 40, 0);
+#elif GCV_XS_SGB == 3                                                   // diagnostic: the vector work, then the four MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x002, 40, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);
     if (gelu_prev && (kc == 10 || kc == 11)) XS_STAMP(32 + 8 * (kc - 10) + j);

@@ -28,6 +28,11 @@ def _read_checkpoint(name):
 
 class GenConViT(nn.Module):
     concurrent = True        # run ED and VAE on two streams when net is the ensemble (class-level switch)
+    # The HIP path always computes fp32 logits.  The reference returns them in the model's dtype (model/genconvit.py:59-61:
+    # after ``.half()`` the networks' last Linear emits fp16, and pred_vid's sigmoid / mean then run in fp16).  Setting
+    # this to True rounds the returned logits to the parameters' dtype, so that ``out.dtype`` and ``y_val`` follow the
+    # reference's --fp16 pipeline; the default keeps the more accurate fp32 tensor.
+    reference_logits_dtype = False
 
     def __init__(self, config, ed, vae, net, fp16):
         super().__init__()
@@ -70,6 +75,13 @@ class GenConViT(nn.Module):
 
     @torch.no_grad()
     def forward(self, x, eps=None):
+        out = self._forward_fp32(x, eps)
+        if self.reference_logits_dtype:
+            m = self.model_ed if self.net != "vae" else self.model_vae
+            out = out.to(m._param_device_dtype()[1])
+        return out
+
+    def _forward_fp32(self, x, eps=None):
         if self.net == "ed":
             return self.model_ed(x)
         if self.net == "vae":

@@ -4,10 +4,12 @@
 # -> genconvit_amd/lib/libgenconvit_hip_<name>.so  (select it with GCV_LIB_PATH)
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); C=$R/genconvit_amd/csrc; N=$1; F=$2; shift 2
-make -C $C -j8 > /dev/null
+# (the normal build must be current: run `make -C genconvit_amd/csrc` first — not from here, so that several variants can be
+#  built in parallel without racing on the build directory)
 mkdir -p $C/build_$N
 OBJS=""
 for o in $C/build/*.o; do
+  case $o in *-hip-amdgcn-*|*-host-*) continue;; esac      # -save-temps by-products
   b=$(basename $o .o); keep=1
   for t in "$@"; do [ "$b" == "$(basename $t .hip)" ] && keep=0; done
   [ $keep == 1 ] && OBJS="$OBJS $o"

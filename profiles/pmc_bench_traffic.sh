@@ -2,11 +2,13 @@
 # HBM traffic of the bench step per kernel family, from rocprofv3 PMC counters (separate passes for FETCH_SIZE and
 # WRITE_SIZE: they do not fit one TCC pass; no trace domains mixed in).  Writes <out>/traffic.json.
 # gfx950: FETCH_SIZE (KB) reads 1/2 of a wide coalesced stream -> doubled (MI355X_MICROARCH.md §HBM); WRITE_SIZE is exact.
+# The runs use --no-concurrent: one stream and the merged two-segment VAE pass in every step, i.e. the schedule bench.py's
+# roofline pass times (the split VAE schedule launches the backbone twice: 78 instead of 60 MLP launches per step).
 # usage: pmc_bench_traffic.sh <outdir> [bench.py args, e.g. --net vae --batch 32 --dtype bf16]
 out=$1; shift; ARGS="$@"; R=${GRAFT_REPO_ROOT:-$PWD}; mkdir -p $R/$out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$out/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 $ARGS > $R/$out/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$out/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 1 $ARGS > $R/$out/write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$out/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-concurrent --profile-steps 1 $ARGS > $R/$out/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$out/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-concurrent --profile-steps 1 $ARGS > $R/$out/write.log 2>&1
 python3 - "$R/$out" $ARGS <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]
@@ -31,7 +33,9 @@ import re
 MLP = ("xs_pw1_kernel", "pw2f_kernel", "xs_mlp_kernel", "fused_mlp_res_kernel", "fused_mlp_kernel", "fused_mlp_ring_kernel")
 def fam(k):
     if any(m in k for m in MLP): return "mfma_gemm"
-    if "gemm_glds_kernel" in k and (re.search(r"gemm_glds_kernel<[^,]+, 1,", k) or re.search(r"gemm_glds_kernel<[^,]+, 0, 2,", k)):
+    # (the counter CSV carries mangled names: gemm_glds_kernelI<T>Li<EPI>ELi<ACT>ELi<BKB>EE; demangled ones are matched too)
+    if "gemm_glds_kernel" in k and (re.search(r"gemm_glds_kernelI\w+?_Li1E", k) or re.search(r"gemm_glds_kernelI\w+?_Li0ELi2E", k) or
+                                    re.search(r"gemm_glds_kernel<[^,]+, 1,", k) or re.search(r"gemm_glds_kernel<[^,]+, 0, 2,", k)):
         return "mfma_gemm"
     if "dwconv7_ln" in k: return "dwconv7_ln"
     return "other"
@@ -63,7 +67,11 @@ for key, lps in expected.items():
     f = res.get(key)
     if f is None or f["dispatches"] != STEPS * lps or f["write_pass_dispatches"] != STEPS * lps:
         bad.append(f"{key}: {None if f is None else (f['dispatches'], f['write_pass_dispatches'])} dispatches recorded, bench.py launches {lps} per step x {STEPS} steps")
-if bad: sys.exit("dispatch count mismatch, traffic.json NOT written:\n  " + "\n  ".join(bad))
+if bad:
+    for key, f in res.items():
+        print(key, f["dispatches"], f["write_pass_dispatches"])
+        for k in sorted(set(f["kernels"])): print("     ", fe[k][0], wr[k][0], k[:120])
+    sys.exit("dispatch count mismatch, traffic.json NOT written:\n  " + "\n  ".join(bad))
 for key, f in res.items():
     n = max(f["dispatches"], 1)
     f["hbm_bytes_per_launch"] = (f["read_bytes"] + f["write_bytes"]) / n

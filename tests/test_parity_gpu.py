@@ -473,6 +473,23 @@ def test_load_genconvit_and_pred_vid_from_published_layout_files(weight_dir, mon
         model.model_vae(x.cuda(), want_kl=True)                   # inference wrapper leaves encoder.var unpacked
 
 
+def test_reference_logits_dtype_opt_in(golden):
+    """model/genconvit.py:59-61: after .half() the reference's logits are fp16; the mirror returns fp32 unless
+    GenConViT.reference_logits_dtype is set, then exactly the fp32 logits rounded to the model dtype."""
+    x = synth.make_frames(4).cuda()
+    eps = torch.from_numpy(golden["vae_eps"]).cuda()
+    g = GenConViT.from_modules(ed_model(torch.float16), vae_model(torch.float16), net="genconvit")
+    a = g(x, eps=eps)
+    try:
+        GenConViT.reference_logits_dtype = True
+        b = g(x, eps=eps)
+    finally:
+        GenConViT.reference_logits_dtype = False
+    assert a.dtype == torch.float32 and b.dtype == torch.float16 and torch.equal(a.half(), b)
+    y = pred_func.max_prediction_value(b)          # the vote accepts the reference's fp16 logits as well
+    assert y[0] in (0, 1)
+
+
 # ----------------------------------------------------------------------------- C boundary: ensemble entry point, RCCL
 def test_genconvit_forward_entry_point_equals_the_two_separate_forwards(golden):
     """gcv_genconvit_forward (model/genconvit.py:66-75 behind one C call: ED and VAE on two internal streams, joined with
