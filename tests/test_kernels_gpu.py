@@ -400,7 +400,9 @@ def test_mean_over_tokens(dt):
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("C,M", [(96, 256), (96, 1000), (192, 300), (192, 37),
                                  (96, 70013),       # >= 65536 tokens at C=96: the LDS-resident persistent kernel
-                                 (384, 128), (384, 1000), (384, 40000)])   # C=384: persistent LDS-DMA weight ring (1 tile, ragged, 2 tiles per CU)
+                                 (192, 70013),      # C=192 x-stationary kernel: 274 passes on 256 workgroups, i.e. a second pass (ring wrap-around, x reload) in some
+                                 (384, 128), (384, 1000), (384, 40000),     # C=384 kernel pair: one tile, ragged, 157 tiles (hidden range split, 256x192 pw2 tiles)
+                                 (384, 60013)])     # ... 235 token tiles: unsplit pw1, full-width 256x384 pw2 tiles, ragged last block
 def test_fused_mlp_layerscale_residual(dt, C, M):
     """timm ConvNeXtBlock tail: fc1 -> exact GELU -> fc2 -> * gamma -> + shortcut, hidden kept on chip."""
     dtype = DTYPES[dt]
