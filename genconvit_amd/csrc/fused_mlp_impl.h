@@ -99,7 +99,9 @@ template <typename T> int launch_fused_mlp(const MlpArgs& a, int C, hipStream_t 
 #ifdef GCV_EXPERIMENTS
   if (mlp_use_ring(C)) return launch_fused_mlp_ring<T>(a, C, s);
 #endif
-  if (C == 192) return launch_mlp_c<T, 192, 8>(a, s);
+#ifdef GCV_EXPERIMENTS
+  if (C == 192) return launch_mlp_c<T, 192, 8>(a, s);   // round-2 streaming kernel: the product runs xs_mlp_kernel at C = 192
+#endif
   set_error("fused MLP kernels of this file: C = 96, 192");
   return -3;
 }
