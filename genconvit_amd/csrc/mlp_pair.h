@@ -9,16 +9,20 @@
 // (~28 B/clk with 64-byte row pieces) bounds the K loop at ~half the matrix rate.  Here
 //   * pw1 keeps a wave's 32 tokens of x_ln in registers as 24 MFMA B fragments for the whole kernel and streams W1 once
 //     per 256 tokens: 24 KB per 32 hidden channels, i.e. 16 B/clk at the full matrix rate, fetched as whole lines because
-//     the packed W1 is contiguous in the order the fragments are read.  The GELU of hidden chunk g-1 (240 vector
-//     instructions) is interleaved 10 : 1 with the 24 MFMAs of chunk g in the same wave, so neither pipe waits for the
-//     other and there is no epilogue phase at all.
+//     the packed W1 is contiguous in the order the fragments are read.  The GELU of hidden chunk g-1 (~150 vector
+//     instructions: polynomial on the packed-fp16 pipe, gemm.h GeluH16) rides between the 24 MFMAs of chunk g in fenced
+//     sub-blocks, so there is no epilogue phase at all.  (Measured, DESIGN.md section 4.0: beside MFMAs every vector
+//     instruction costs ~4 issue cycles whatever the arrangement, so what counts is how few there are: 8.5 per MFMA here,
+//     12 in the tile GEMM's epilogue.)
 //   * the hidden tensor is stored FRAGMENT-MAJOR: block (token block tb of 32, hidden chunk kc of 32) is 2 KB laid out
 //     [kq = 4][token = 32][8 hidden] — one 16-byte piece per lane, exactly an MFMA operand fragment.  pw1 writes a block
 //     with two contiguous 1 KB store instructions; pw2 fetches blocks with linear 1 KB LDS-DMA pieces (whole lines at a
 //     K step of 32) and reads fragments with `base + immediate` ds_read_b128, conflict-free without a swizzle.
 //   * W1 / W2 are packed once at load time in the same fragment order (pack_w1_frag / pack_w2_frag).
-//   * rings are deep (6 x 24 KB, 3 x 40 KB): a DMA takes 1-2 us from issue to landing under load, so the prefetch
-//     distance is sized in time (>= 3000 cycles), one workgroup of 8 waves per CU.
+//   * rings are sized in time, not in stages: a DMA takes 1-2 us from issue to landing under load, so pw1 runs 6 x 24 KB
+//     (four chunks ahead), pw2 3 x 40 KB or 5 x 28 KB; one workgroup of 8 waves per CU.
+// Measured at 256 images (rocprofv3): pw1 80 us (tile GEMM 106), pw2 83 us (tile GEMM ~100); timelines and ablations:
+// profiles/xs_stamps.py, p2_stamps.py, GCV_XS_ABLATE / GCV_P2_ABLATE builds, DESIGN.md section 4.0.
 #pragma once
 #include <type_traits>
 
