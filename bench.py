@@ -192,7 +192,7 @@ def main():
     dtype = DT[a.dtype]
     GenConViT.concurrent = not a.no_concurrent
     if a.no_concurrent:
-        os.environ["GCV_VAE_SPLIT"] = "0"      # one stream for everything: the VAE keeps backbone(x) behind its codec too
+        os.environ["GCV_VAE_SPLIT"] = "0"      # one stream for everything (also the library's default since round 3)
     nets = 2 if a.net == "genconvit" else 1
     model, sds = build_models(a.net, dtype, a.batch, device)
     log("models built (synthetic weights generated on device)")

@@ -255,7 +255,11 @@ int gcv_genconvit_forward(gcv_handle* he, gcv_handle* hv, const void* x_nchw, co
   GCV_CHECK_HIP(hipStreamWaitEvent(he->side[0], he->ev_fork, 0));
   GCV_CHECK_HIP(hipStreamWaitEvent(he->side[1], he->ev_fork, 0));
   int rc = he->net->ed_forward(x_nchw, batch, logits, he->side[0]);
-  if (!rc) rc = hv->net->vae_forward(x_nchw, eps, batch, logits + (size_t)batch * 2, nullptr, nullptr, nullptr, he->side[1]);
+  if (!rc) {
+    hv->net->in_ensemble = true;           // schedule hint: merged backbone pass (net_impl.h, vae_split_env)
+    rc = hv->net->vae_forward(x_nchw, eps, batch, logits + (size_t)batch * 2, nullptr, nullptr, nullptr, he->side[1]);
+    hv->net->in_ensemble = false;
+  }
   // join even after an error: whatever was enqueued must be ordered before the caller's next work on `stream`
   for (int i = 0; i < 2; ++i) {
     if (hipEventRecord(he->ev_join[i], he->side[i]) == hipSuccess) (void)hipStreamWaitEvent(s, he->ev_join[i], 0);

@@ -41,6 +41,7 @@ struct NetBase {
   int dtype = 0;
   int max_batch = 0;
   Profiler prof;
+  bool in_ensemble = false;   // set by gcv_genconvit_forward around vae_forward: the VAE shares the GPU with the ED network
   virtual ~NetBase() {}
   virtual int init() = 0;
   virtual int load_ed(const TensorMap& w) = 0;

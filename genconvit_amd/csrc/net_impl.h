@@ -159,9 +159,14 @@ template <typename T> struct NetImpl : NetBase {
   bool use_fused_mlp384 = exp_env("GCV_FUSED_MLP384") != nullptr;
   bool use_mlp_pair = exp_env("GCV_NO_MLP_PAIR") == nullptr;     // C = 384: pw1 / pw2 kernel pair (mlp_pair.h)
   bool use_xs_mlp = exp_env("GCV_MLP_LEGACY") == nullptr;        // C = 192: x-stationary fused MLP (xs_mlp.h)
-  // vae_forward runs backbone(x) — which depends on nothing but the input — on a side stream while the encoder / mu GEMM /
-  // decoder chain (small, latency-bound launches) runs on the caller's stream; GCV_VAE_SPLIT=0 is the A/B switch
-  bool vae_split = [] { const char* e = std::getenv("GCV_VAE_SPLIT"); return e ? std::atoi(e) != 0 : true; }();
+  // Schedule of vae_forward.  SPLIT: backbone(x) — which depends on nothing but the input — runs on a side stream while
+  // the encoder / mu GEMM / decoder chain (small, latency-bound launches) and then backbone(x_hat) run on the caller's
+  // stream.  MERGED: one stream, one two-segment backbone pass.  Alone on the GPU the split hides the codec chain
+  // (vae B=32 bf16: 18.3k vs 15.2k frames/s); inside gcv_genconvit_forward the ED network already fills those gaps and
+  // the merged pass wins (7.49 vs 7.58-7.62 ms per step in paired runs: the round-3 MLP kernels pay per 256-token pass
+  // and prefer one launch over two smaller ones).  Default: split when called on its own, merged inside the ensemble;
+  // GCV_VAE_SPLIT=0 / 1 forces one of them.  Both are under test (tests/test_parity_gpu.py, fresh_vae).
+  int vae_split_env = [] { const char* e = std::getenv("GCV_VAE_SPLIT"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();
   hipStream_t vae_side = nullptr;                      // (one per handle; the ED and the VAE network are separate handles)
   hipEvent_t vae_fork = nullptr, vae_join = nullptr;
   // the caller's stream waits for the side stream before the head reads its half of `feat` — and on every early return,
@@ -775,7 +780,7 @@ template <typename T> struct NetImpl : NetBase {
     Seg<T> segs[2];
     segs[0] = Seg<T>{x, (int64_t)3 * 224 * 224, 224 * 224, 224, 1, B, 224, 224, feat, 2000, ACT_RELU};
     segs[1] = Seg<T>{xhat, (int64_t)112 * 112 * 3, 1, 112 * 3, 3, B, 112, 112, feat + 1000, 2000, ACT_RELU};
-    const bool split = vae_split && !prof.enabled;       // (profiled steps stay on one stream: serial per-kernel times)
+    const bool split = (vae_split_env >= 0 ? vae_split_env != 0 : !in_ensemble) && !prof.enabled;   // (profiled steps stay on one stream: serial per-kernel times)
     Join join;
     if (split) GCV_TRY(side_pass(bb_vae, &segs[0], s, join));
 
@@ -868,6 +873,9 @@ template <typename T> struct NetImpl : NetBase {
     arena.off = arena.peak = 0;
     int rc = ed_forward(nullptr, max_batch, nullptr, nullptr);
     if (!rc) rc = vae_forward(nullptr, nullptr, max_batch, nullptr, nullptr, nullptr, nullptr, nullptr);
+    in_ensemble = true;                    // both VAE schedules (see vae_split_env): the arena holds the larger footprint
+    if (!rc) rc = vae_forward(nullptr, nullptr, max_batch, nullptr, nullptr, nullptr, nullptr, nullptr);
+    in_ensemble = false;
     if (!rc) rc = swin_forward(nullptr, max_batch, nullptr, nullptr);
     arena.dry = false;
     if (rc) return rc;

@@ -75,10 +75,12 @@ int gcv_ed_forward(gcv_handle* h, const void* x_nchw, int batch, float* logits, 
  *   mse      : nullable, (B) fp32 per-frame mean((recon224 - x)^2); its mean is the reference's
  *              nn.MSELoss()(recons, images) (train/train_vae.py:24,76)
  *   kl       : nullable, (1) fp32 = Encoder.kl (model/genconvit_vae.py:58)
- * backbone(x) (:111) depends on nothing but the input: it is enqueued on a side stream owned by the handle, forked
- * from `stream` at the call and joined back into it by an event before the head, while the encoder / decoder chain and
- * backbone(x_hat) run on `stream` itself.  For the caller nothing changes: all work is ordered after what `stream` held
- * at the call and before what it is given next; no synchronisation.  (GCV_VAE_SPLIT=0 keeps everything on `stream`.) */
+ * backbone(x) (:111) depends on nothing but the input: called on its own, gcv_vae_forward enqueues it on a side stream
+ * owned by the handle, forked from `stream` at the call and joined back into it by an event before the head, while the
+ * encoder / decoder chain and backbone(x_hat) run on `stream` itself; inside gcv_genconvit_forward everything of the VAE
+ * stays on one stream.  GCV_VAE_SPLIT=0 / 1 (read when the handle is created) forces the merged / the split schedule.
+ * Either way nothing changes for the caller: all work is ordered after what `stream` held at the call and before what
+ * it is given next; no synchronisation. */
 int gcv_vae_forward(gcv_handle* h, const void* x_nchw, const float* eps, int batch, float* logits,
                     void* recon224, float* mse, float* kl, gcv_stream stream);
 
