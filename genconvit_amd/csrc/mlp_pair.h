@@ -82,6 +82,9 @@ template <int C, int NW, int D> struct XsPw1Smem {
 #ifndef GCV_XS_ABLATE
 #define GCV_XS_ABLATE 0    // diagnostic builds only: 1 = no GELU arithmetic, 2 = no DMA after the prologue, 4 = no stores,
 #endif                     //                         8 = no MFMA, 16 = no fragment reads after the first
+#ifndef GCV_XS_PAIR
+#define GCV_XS_PAIR 1     // two hidden chunks per barrier (0: one, the first version of the kernel)
+#endif
 #ifndef GCV_XS_SGB
 #define GCV_XS_SGB 1      // 1 = 1 MFMA : 1 LDS read : n vector instructions (product); 0 / 2 / 3 diagnostics, see sub_block
 #endif
@@ -198,7 +201,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) xs_pw1_kernel(const MlpPairAr
   //  86 us against 80 us at 256 images.  An LDS-DMA instruction costs its SIMD the same issue time wherever it sits.)
   XS_STAMP(0);
 #pragma unroll
-  for (int s = 0; s < D - 1; ++s) issue();
+  for (int s = 0; s < (GCV_XS_PAIR ? D - 2 : D - 1); ++s) issue();
 
   // hidden tensor as a buffer: blocks of token blocks >= ntb are out of range and their stores are dropped
   const __amdgpu_buffer_rsrc_t rsh =
@@ -300,11 +303,6 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) xs_pw1_kernel(const MlpPairAr
     __builtin_amdgcn_sched_barrier(0);
     if (gelu_prev && (kc == 10 || kc == 11)) XS_STAMP(32 + 8 * (kc - 10) + j);
   };
-  // One step: chunk `kc` lands, its 24 MFMAs go into `nxt` while the GELU of chunk kc-1 (in `cur`) runs in their shadow.
-  // Wait count: the DMAs of chunk kc were issued D-1 steps ago; younger than them are the (D-2) * PPW DMAs of chunks
-  // kc+1 .. kc+D-2 and the 2 stores of each step since.  vmcnt((D-2) * PPW) ignores the stores, i.e. it asks for a
-  // little more than needed (the oldest chunk still in flight must have part-landed) and is also right for the first
-  // steps, which have no stores behind them.
 #define GCV_XS_SUBBLOCKS(cur, nxt, kc, G)                                                      \
   sub_block(cur, nxt, kc, std::integral_constant<int, 0>{}, std::integral_constant<bool, G>{}); \
   sub_block(cur, nxt, kc, std::integral_constant<int, 1>{}, std::integral_constant<bool, G>{}); \
@@ -312,40 +310,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) xs_pw1_kernel(const MlpPairAr
   sub_block(cur, nxt, kc, std::integral_constant<int, 3>{}, std::integral_constant<bool, G>{}); \
   sub_block(cur, nxt, kc, std::integral_constant<int, 4>{}, std::integral_constant<bool, G>{}); \
   sub_block(cur, nxt, kc, std::integral_constant<int, 5>{}, std::integral_constant<bool, G>{})
-  auto step = [&](f32x16& cur, f32x16& nxt, int kc) {
-    if (kc >= 8 && kc < 16) XS_STAMP(2 * kc);
-    GCV_XS_WAIT(WAITN);
-    if (kc >= 8 && kc < 16) XS_STAMP(2 * kc + 1);
-    if (!(GCV_XS_ABLATE & 2)) issue();
-    sw = smem + slot_r * SLOT + lane * 16;
-    slot_r = slot_r + 1 == D ? 0 : slot_r + 1;
-    read_bias(nxt, kc);
-    read_frags(0);
-    __builtin_amdgcn_sched_barrier(0);
-    GCV_XS_SUBBLOCKS(cur, nxt, kc, true);
-  };
   static_assert(KP == 24, "the sub-block schedule is written for K = 384");
-
-  f32x16 accA, accB;
-  // step 0: nothing to activate yet; the first wait also covers the x loads (older than every DMA)
-  GCV_XS_WAIT(WAITN);
-#pragma unroll
-  for (int p = 0; p < KP; ++p) asm volatile("" : "+v"(xf[p]));   // no use of xf may move above the wait
-  issue();
-  slot_r = 1;
-  read_bias(accA, 0);
-  read_frags(0);
-  __builtin_amdgcn_sched_barrier(0);
-  GCV_XS_SUBBLOCKS(accA, accA, 0, false);
-  int kc = 1;
-#pragma unroll 1
-  for (; kc + 1 < nch; kc += 2) {
-    step(accA, accB, kc);
-    step(accB, accA, kc + 1);
-  }
-  // the last chunk's GELU has no MFMAs to hide under
-  XS_STAMP(1);
-  auto gelu_tail = [&](const f32x16& acc, int kcl) {
+  auto gelu_tail = [&](const f32x16& acc, int kcl) {       // the last chunk's GELU has no MFMAs to hide under
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       gelu_a(acc, half);
@@ -353,12 +319,68 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) xs_pw1_kernel(const MlpPairAr
       gelu_c(acc, half, kcl);
     }
   };
+  // the MFMAs of chunk kc into `nxt` with the GELU of chunk kc-1 (in `cur`) in their shadow; the chunk's slot is current
+  auto chunk = [&](f32x16& cur, f32x16& nxt, int kc, auto gc) {
+    sw = smem + slot_r * SLOT + lane * 16;
+    slot_r = slot_r + 1 == D ? 0 : slot_r + 1;
+    read_bias(nxt, kc);
+    read_frags(0);
+    __builtin_amdgcn_sched_barrier(0);
+    GCV_XS_SUBBLOCKS(cur, nxt, kc, decltype(gc)::value);
+  };
+  f32x16 accA, accB;
+#if GCV_XS_PAIR
+  // TWO chunks per barrier (nch is even: launcher): at the head of pair (kc, kc+1) the ring holds chunks kc .. kc+3, the
+  // slots of kc-2 and kc-1 are free; both needed chunks have landed when at most the 2 * PPW pieces of kc+2, kc+3 are
+  // outstanding (the stores of the previous pair are younger still: the count is conservative by them)
+  constexpr int WAITP = 2 * PPW;
+  GCV_XS_WAIT(WAITP);
+#pragma unroll
+  for (int p = 0; p < KP; ++p) asm volatile("" : "+v"(xf[p]));   // no use of xf may move above the wait
+  issue();
+  issue();
+  chunk(accB, accA, 0, std::false_type{});
+  chunk(accA, accB, 1, std::true_type{});
+#pragma unroll 1
+  for (int kc = 2; kc < nch; kc += 2) {
+    if (kc >= 8 && kc < 16) XS_STAMP(2 * kc);
+    GCV_XS_WAIT(WAITP);
+    if (kc >= 8 && kc < 16) XS_STAMP(2 * kc + 1);
+    if (!(GCV_XS_ABLATE & 2)) { issue(); issue(); }
+    chunk(accB, accA, kc, std::true_type{});
+    chunk(accA, accB, kc + 1, std::true_type{});
+  }
+  XS_STAMP(1);
+  gelu_tail(accB, nch - 1);
+#else
+  // One chunk per barrier.  Wait count: the DMAs of chunk kc were issued D-1 steps ago; younger than them are the
+  // (D-2) * PPW DMAs of chunks kc+1 .. kc+D-2 and the 2 stores of each step since; vmcnt((D-2) * PPW) ignores the stores
+  auto step = [&](f32x16& cur, f32x16& nxt, int kc) {
+    if (kc >= 8 && kc < 16) XS_STAMP(2 * kc);
+    GCV_XS_WAIT(WAITN);
+    if (kc >= 8 && kc < 16) XS_STAMP(2 * kc + 1);
+    if (!(GCV_XS_ABLATE & 2)) issue();
+    chunk(cur, nxt, kc, std::true_type{});
+  };
+  GCV_XS_WAIT(WAITN);
+#pragma unroll
+  for (int p = 0; p < KP; ++p) asm volatile("" : "+v"(xf[p]));   // no use of xf may move above the wait
+  issue();
+  chunk(accA, accA, 0, std::false_type{});
+  int kc = 1;
+#pragma unroll 1
+  for (; kc + 1 < nch; kc += 2) {
+    step(accA, accB, kc);
+    step(accB, accA, kc + 1);
+  }
+  XS_STAMP(1);
   if (kc < nch) {                                          // nch even: one more chunk, it ends up in accB
     step(accA, accB, kc);
     gelu_tail(accB, kc);
   } else {
     gelu_tail(accA, kc - 1);
   }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // no DMA may outlive the workgroup's LDS
   XS_STAMP(2);
 }

@@ -52,6 +52,7 @@ template <typename T, int C> static int launch_xs_pw1_c(const MlpPairArgs& a, hi
   GCV_ENSURE_LDS((xs_pw1_kernel<T, C, NW, D>), SMEM);
   const int ntile = cdiv(a.M, 32 * NW);
   const int ns = xs_pw1_pick_split(ntile, NKC);
+  GCV_REQUIRE((NKC / ns) % 2 == 0, "xs_pw1: an even number of hidden chunks per workgroup (two per barrier)");
   hipLaunchKernelGGL((xs_pw1_kernel<T, C, NW, D>), dim3(ntile, ns), dim3(NW * 64), SMEM, s, a, NKC / ns);
   GCV_CHECK_HIP(hipGetLastError());
   return 0;

@@ -106,11 +106,11 @@ __global__ void __launch_bounds__(512, 2) xs_mlp_kernel(const XsMlpArgs a, const
   typedef XsMlpCfg<C> CF;
   constexpr int KP1 = CF::KP1, NO = CF::NO, NM = CF::NM, REC = CF::REC, NKC = CF::NKC, D = CF::D, PPW = CF::PPW;
   constexpr int NLW = CF::NLW, NSB = CF::NSB;
-  // chunk n is needed at step n; its slot is reused by chunk n + D once W2[n] has been consumed at step n + 2, i.e. the
-  // refill issued at step n goes to the slot of chunk n - 3 and carries chunk n + D - 3.  At the wait of step n the DMAs
-  // younger than chunk n's are those of chunks n + 1 .. n + D - 4
-  constexpr int WAITN = (D - 4) * PPW;
-  static_assert(D >= 5, "ring: one slot being filled, W1 of this step, W2 of the two steps before");
+  // Ring, TWO steps per barrier: chunk n is needed at step n (W1 part) and at step n + 2 (W2 part).  At the head of the pair
+  // (n, n+1), n even, chunks n-2 .. n+1 are live, the slots of n-4 and n-3 are dead (W2[n-3] was consumed at step n-1) and
+  // take chunks n+2 and n+3; the only DMAs outstanding before that refill are those of chunks n and n+1, issued one pair
+  // earlier (~6000 cycles): vmcnt(0).  4 live + 2 incoming = 6 slots.
+  static_assert(D >= 6 && NKC % 2 == 0, "ring: four live chunks and two incoming; passes are whole pairs of steps");
   typedef T t4 __attribute__((ext_vector_type(4)));
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -147,8 +147,8 @@ __global__ void __launch_bounds__(512, 2) xs_mlp_kernel(const XsMlpArgs a, const
     gw = gw + 1 == NKC ? 0 : gw + 1;
     slot_w = slot_w + 1 == D ? 0 : slot_w + 1;
   };
-#pragma unroll
-  for (int s = 0; s < D - 3; ++s) issue();                 // chunks 0 .. D-4
+  issue();
+  issue();                                                 // chunks 0 and 1
 
   const float* const sb1 = reinterpret_cast<const float*>(smem + CF::kB1) + 4 * lh;
   const float* const sB2_ = reinterpret_cast<const float*>(smem + CF::kBG);
@@ -229,11 +229,11 @@ __global__ void __launch_bounds__(512, 2) xs_mlp_kernel(const XsMlpArgs a, const
     auto step = [&](f32x16& cur1, f32x16& nxt1, u32x4 (&hfp)[2], u32x4 (&hfc)[2], int kc, auto g1c, auto glc, auto g2c,
                     auto ringc) {
       constexpr bool G1 = decltype(g1c)::value, GL = decltype(glc)::value, G2 = decltype(g2c)::value;
-      constexpr bool RING = decltype(ringc)::value;
+      constexpr int RING = decltype(ringc)::value;                      // 0: drain step, 1: head of a pair, 2: its second step
       constexpr int I0 = G1 ? 0 : KP1, I1 = G2 ? NM : KP1;              // MFMA ops of this step
-      if (RING) {
-        GCV_XM_WAIT(WAITN);
-        if (!(GCV_XM_ABLATE & 2)) issue();
+      if (RING == 1) {
+        GCV_XM_WAIT(0);
+        if (!(GCV_XM_ABLATE & 2)) { issue(); issue(); }
       }
       const unsigned char* s1 = smem + slot1 * REC + lane16;
       const unsigned char* s2 = smem + slot_dec(slot1, 2) * REC + lane16;
@@ -287,18 +287,21 @@ __global__ void __launch_bounds__(512, 2) xs_mlp_kernel(const XsMlpArgs a, const
     };
     using TT = std::true_type;
     using FF = std::false_type;
+    using R0 = std::integral_constant<int, 0>;
+    using R1 = std::integral_constant<int, 1>;
+    using R2 = std::integral_constant<int, 2>;
 
     f32x16 accA, accB;
     u32x4 hfA[2], hfB[2];
     if (it == 0) XM_STAMP(1);
-    step(accA, accA, hfA, hfA, 0, TT{}, FF{}, FF{}, TT{});               // g = 0: GEMM1(0) -> A
-    step(accA, accB, hfA, hfA, 1, TT{}, TT{}, FF{}, TT{});               // g = 1: GEMM1(1) -> B, h(0) -> hfA
+    step(accA, accA, hfA, hfA, 0, TT{}, FF{}, FF{}, R1{});               // g = 0: GEMM1(0) -> A
+    step(accA, accB, hfA, hfA, 1, TT{}, TT{}, FF{}, R2{});               // g = 1: GEMM1(1) -> B, h(0) -> hfA
     if (it == 0) XM_STAMP(2);
     // steady state, two steps per iteration: (cur A->hfB | GEMM2 hfA) then (cur B->hfA | GEMM2 hfB)
 #pragma unroll 1
     for (int g = 2; g < NKC; g += 2) {
-      step(accB, accA, hfA, hfB, g, TT{}, TT{}, TT{}, TT{});             // GEMM1(g) -> A, h(g-1) = GELU(B) -> hfB, GEMM2(g-2) hfA
-      step(accA, accB, hfB, hfA, g + 1, TT{}, TT{}, TT{}, TT{});         // GEMM1(g+1) -> B, h(g) = GELU(A) -> hfA, GEMM2(g-1) hfB
+      step(accB, accA, hfA, hfB, g, TT{}, TT{}, TT{}, R1{});             // GEMM1(g) -> A, h(g-1) = GELU(B) -> hfB, GEMM2(g-2) hfA
+      step(accA, accB, hfB, hfA, g + 1, TT{}, TT{}, TT{}, R2{});         // GEMM1(g+1) -> B, h(g) = GELU(A) -> hfA, GEMM2(g-1) hfB
     }
     if (it == 0) XM_STAMP(3);
     // residual rows into the (now dead) x registers: 16-byte pieces, lanes 0-31 channels 16p .. 16p+7, lanes 32-63 the
@@ -309,9 +312,9 @@ __global__ void __launch_bounds__(512, 2) xs_mlp_kernel(const XsMlpArgs a, const
     for (int p = 0; p < KP1; ++p) rres[p] = *(const u32x4*)(Rp + mc * C + 16 * p + 8 * lh);
     // drain (the ring is not touched: no barrier): h(NKC-1) = GELU(B) -> hfB with GEMM2(NKC-2) hfA, then GEMM2(NKC-1) hfB.
     // slot1 already points one past the last chunk: GEMM2's "slot g-2" is slot1 - 2 for chunk NKC-2, slot1 - 1 for NKC-1
-    step(accB, accA, hfA, hfB, 0, FF{}, TT{}, TT{}, FF{});
+    step(accB, accA, hfA, hfB, 0, FF{}, TT{}, TT{}, R0{});
     slot1 = slot1 + 1 == D ? 0 : slot1 + 1;
-    step(accB, accA, hfB, hfA, 0, FF{}, FF{}, TT{}, FF{});
+    step(accB, accA, hfB, hfA, 0, FF{}, FF{}, TT{}, R0{});
     slot1 = slot_dec(slot1, 1);
     if (it == 0) XM_STAMP(4);
 
