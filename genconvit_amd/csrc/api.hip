@@ -122,35 +122,63 @@ static int to_map(const gcv_tensor_desc* w, int n, TensorMap& m) {
 
 // ConvNeXt MLP (16-bit only): W1 is given as (4C, C) T, W2 as plain (C, 4C) fp32 on the device; both are packed here.
 // C = 96 / 192: the fused kernels; C = 384: the pw1 / pw2 kernel pair with its fragment-major hidden tensor.
+// iters == 0: one launch.  iters > 0 (gcv_k_fused_mlp_timed): the weights are packed once, then `iters` launches are timed
+// with HIP events on the stream; ms[0] = average of the whole MLP, ms[1] / ms[2] = pw1 / pw2 of the C = 384 pair (else 0).
 template <typename T>
 static int k_mlp_dispatch(int C, const void* x, const void* w1, const float* b1, const float* w2_f32, const float* b2,
-                          const float* gamma, const void* resid, void* out, int M, hipStream_t s) {
+                          const float* gamma, const void* resid, void* out, int M, hipStream_t s, int iters = 0,
+                          float* ms = nullptr) {
   struct DevBuf {                                  // freed on every exit path (after the stream has drained)
     void* p = nullptr;
     hipStream_t s;
     explicit DevBuf(hipStream_t st) : s(st) {}
     ~DevBuf() { if (p) { (void)hipStreamSynchronize(s); (void)hipFree(p); } }
   };
+  struct Ev {
+    hipEvent_t e = nullptr;
+    ~Ev() { if (e) (void)hipEventDestroy(e); }
+  };
   DevBuf w2c(s), w1f(s), hid(s);
   GCV_CHECK_HIP(hipMalloc(&w2c.p, (size_t)4 * C * C * 2));
+  // timed(f, &avg): warm-up launch, then `iters` launches between two events
+  auto timed = [&](auto&& f, float* avg) -> int {
+    if (iters <= 0) return f();
+    Ev e0, e1;
+    GCV_CHECK_HIP(hipEventCreate(&e0.e));
+    GCV_CHECK_HIP(hipEventCreate(&e1.e));
+    GCV_TRY(f());
+    GCV_CHECK_HIP(hipEventRecord(e0.e, s));
+    for (int i = 0; i < iters; ++i) GCV_TRY(f());
+    GCV_CHECK_HIP(hipEventRecord(e1.e, s));
+    GCV_CHECK_HIP(hipEventSynchronize(e1.e));
+    float t = 0.0f;
+    GCV_CHECK_HIP(hipEventElapsedTime(&t, e0.e, e1.e));
+    if (avg) *avg = t / (float)iters;
+    return 0;
+  };
+  if (ms) ms[0] = ms[1] = ms[2] = 0.0f;
   if (mlp_pair_supported(C)) {
     GCV_CHECK_HIP(hipMalloc(&w1f.p, (size_t)4 * C * C * 2));
     GCV_CHECK_HIP(hipMalloc(&hid.p, mlp_pair_hidden_bytes(M, C)));
     GCV_TRY((launch_pack_w1_frag<T, T>((const T*)w1, (T*)w1f.p, C, s)));
     GCV_TRY((launch_pack_w2_frag<T, float>(w2_f32, (T*)w2c.p, C, s)));
     MlpPairArgs a{x, w1f.p, b1, w2c.p, b2, gamma, resid, out, hid.p, M};
-    return launch_mlp_pair<T>(a, C, s);
+    if (iters > 0) {
+      GCV_TRY(timed([&] { return launch_xs_pw1<T>(a, C, s); }, ms ? ms + 1 : nullptr));
+      GCV_TRY(timed([&] { return launch_pw2f<T>(a, C, s); }, ms ? ms + 2 : nullptr));
+    }
+    return timed([&] { return launch_mlp_pair<T>(a, C, s); }, ms);
   }
   static const bool legacy = exp_env("GCV_MLP_LEGACY") != nullptr;   // A/B: the round-2 fused kernels
   if (xs_mlp_default(C) && !legacy) {
     GCV_CHECK_HIP(hipMalloc(&w1f.p, xs_mlp_packed_elems(C) * sizeof(T)));
     GCV_TRY((launch_pack_xs_mlp<T, float>((const T*)w1, w2_f32, (T*)w1f.p, C, s)));
     XsMlpArgs xa{x, w1f.p, b1, b2, gamma, resid, out, M};
-    return launch_xs_mlp<T>(xa, C, s);
+    return timed([&] { return launch_xs_mlp<T>(xa, C, s); }, ms);
   }
   MlpArgs a{x, w1, b1, w2c.p, b2, gamma, resid, out, M};
   GCV_TRY(launch_pack_w2_chunks<T>(w2_f32, (T*)w2c.p, C, s));
-  return launch_fused_mlp<T>(a, C, s);
+  return timed([&] { return launch_fused_mlp<T>(a, C, s); }, ms);
 }
 
 extern "C" {
@@ -484,6 +512,16 @@ int gcv_k_fused_mlp(int dtype, int C, const void* x, const void* w1, const float
   GCV_REQUIRE(dtype == GCV_F16 || dtype == GCV_BF16, "the MLP kernels are built for 16-bit storage");
   if (dtype == GCV_F16) return k_mlp_dispatch<half_t>(C, x, w1, b1, w2_f32, b2, gamma, resid, out, M, (hipStream_t)s);
   return k_mlp_dispatch<bf16_t>(C, x, w1, b1, w2_f32, b2, gamma, resid, out, M, (hipStream_t)s);
+}
+
+int gcv_k_fused_mlp_timed(int dtype, int C, const void* x, const void* w1, const float* b1, const float* w2_f32,
+                          const float* b2, const float* gamma, const void* resid, void* out, int M, int iters,
+                          float* ms3, gcv_stream s) {
+  GCV_REQUIRE(dtype == GCV_F16 || dtype == GCV_BF16, "the MLP kernels are built for 16-bit storage");
+  GCV_REQUIRE(iters >= 1 && ms3 != nullptr, "gcv_k_fused_mlp_timed: iters >= 1 and a float[3] for the averages");
+  if (dtype == GCV_F16)
+    return k_mlp_dispatch<half_t>(C, x, w1, b1, w2_f32, b2, gamma, resid, out, M, (hipStream_t)s, iters, ms3);
+  return k_mlp_dispatch<bf16_t>(C, x, w1, b1, w2_f32, b2, gamma, resid, out, M, (hipStream_t)s, iters, ms3);
 }
 
 }  // extern "C"

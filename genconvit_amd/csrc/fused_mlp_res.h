@@ -173,19 +173,18 @@ __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) 
     auto gelu = [&](const f32x16& acc1, u32x4 (&hf)[2]) {
 #pragma unroll
       for (int q0 = 0; q0 < 4; q0 += 2) {
-        float hv[2][4];
+        float hx[8];
 #pragma unroll
-        for (int qq = 0; qq < 2; ++qq)
+        for (int c = 0; c < 8; ++c) hx[c] = acc1[4 * q0 + c];
+        uint32_t hw[4];
+        if (!(GCV_MLP_ABLATE & 1)) gelu_h16_frag<T, 8>(hx, hw);
+        else {
+          typedef T t2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-          for (int e = 0; e < 4; ++e) hv[qq][e] = acc1[4 * (q0 + qq) + e];
-        if (!(GCV_MLP_ABLATE & 1)) act4n<ACT_GELU, T, 2>(hv);
-#pragma unroll
-        for (int qq = 0; qq < 2; ++qq) {
-          const t4 h4 = {from_f<T>(hv[qq][0]), from_f<T>(hv[qq][1]), from_f<T>(hv[qq][2]), from_f<T>(hv[qq][3])};
-          const uint2 pk = __builtin_bit_cast(uint2, h4);
-          hf[q0 >> 1][2 * qq] = pk.x;
-          hf[q0 >> 1][2 * qq + 1] = pk.y;
+          for (int c = 0; c < 4; ++c) hw[c] = __builtin_bit_cast(uint32_t, (t2){from_f<T>(hx[2 * c]), from_f<T>(hx[2 * c + 1])});
         }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) hf[q0 >> 1][c] = hw[c];
       }
     };
     // one steady-state step for group g: C holds GEMM1(g)+b1, N holds b1(g+1), hp = h(g-1), wf = W1(g+1), w2f = W2(g-1)
@@ -196,7 +195,7 @@ __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) 
       gelu(Cacc, hc);
 #pragma unroll
       for (int i = 0; i < 12; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x002, 15, 0);   // 15 VALU
+        __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);   // 11 VALU
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
       }
       __builtin_amdgcn_sched_barrier(0);

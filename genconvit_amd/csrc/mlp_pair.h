@@ -143,7 +143,6 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) xs_pw1_kernel(const MlpPairAr
   constexpr int PPW = NPC / NW;
   constexpr int WAITN = (D - 2) * PPW;                     // see the count at step()
   constexpr int NKC = 4 * C / 32;                          // hidden chunks in all
-  typedef T t4 __attribute__((ext_vector_type(4)));
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -220,25 +219,20 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) xs_pw1_kernel(const MlpPairAr
   // pairs and the GELU behind them, one dependent v_pk_fma chain at a time.)
   GeluH16::State<4> gst;                                   // GELU state of the half chunk (8 values) in flight
   float gx[8];
-  auto gelu_a = [&](const f32x16& acc, int half) {         // |x| clamp -> fp16, t, Horner levels 10 .. 6
+  auto gelu_a = [&](const f32x16& acc, int half) {         // |x| clamp -> fp16, t, Horner levels 8 .. 6
 #pragma unroll
     for (int c = 0; c < 8; ++c) gx[c] = acc[8 * half + c];
     GeluH16::begin<4, 6>(gx, gst);
   };
-  auto gelu_b = [&]() { GeluH16::horner<4, 5, 0>(gst); };  // Horner levels 5 .. 0
+  auto gelu_b = [&]() { GeluH16::horner<4, 5, 2>(gst); };  // Horner levels 5 .. 2
   // max(x, 0) - h -> 16-bit -> one 1 KB half of the block.  Lane (token, lh) holds channels 8q + 4lh + e; one
   // v_permlane32_swap per dword of a (q, q+1) pair gives lanes 0-31 the 16 bytes of piece q and lanes 32-63 those of
   // piece q+1, i.e. the wave stores [kq][token][8] in lane order.
   auto gelu_c = [&](const f32x16& acc, int half, int kc) {
-    float gy[8];
-    GeluH16::finish<4>(gx, gst, gy);
-    uint2 pk[2];
-#pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {
-      const float* v = gy + 4 * qq;
-      const t4 h4 = {from_f<T>(v[0]), from_f<T>(v[1]), from_f<T>(v[2]), from_f<T>(v[3])};
-      pk[qq] = __builtin_bit_cast(uint2, h4);
-    }
+    uint32_t hw[4];
+    GeluH16::horner<4, 1, 0>(gst);                         // Horner levels 1, 0
+    GeluH16::finish_frag<T, 4>(gx, gst, hw);
+    const uint2 pk[2] = {uint2{hw[0], hw[1]}, uint2{hw[2], hw[3]}};
     u32x4 w;
     if (!(GCV_XS_ABLATE & 32)) {
       const auto sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);

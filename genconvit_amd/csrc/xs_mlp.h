@@ -195,23 +195,19 @@ __global__ void __launch_bounds__(512, 2) xs_mlp_kernel(const XsMlpArgs a, const
     auto gelu_a = [&](const f32x16& acc, int half) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) gx[c] = acc[8 * half + c];
-      if (!(GCV_XM_ABLATE & 1)) GeluH16::begin<4, 6>(gx, gst);
+      if (!(GCV_XM_ABLATE & 1)) GeluH16::begin<4, 5>(gx, gst);
     };
-    auto gelu_b = [&]() { if (!(GCV_XM_ABLATE & 1)) GeluH16::horner<4, 5, 0>(gst); };
+    auto gelu_b = [&]() { if (!(GCV_XM_ABLATE & 1)) GeluH16::horner<4, 4, 0>(gst); };
     auto gelu_c = [&](u32x4& hf) {
-      float gy[8];
-      if (!(GCV_XM_ABLATE & 1)) GeluH16::finish<4>(gx, gst, gy);
+      uint32_t hw[4];
+      if (!(GCV_XM_ABLATE & 1)) GeluH16::finish_frag<T, 4>(gx, gst, hw);
       else {
+        typedef T t2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int c = 0; c < 8; ++c) gy[c] = gx[c];
+        for (int c = 0; c < 4; ++c) hw[c] = __builtin_bit_cast(uint32_t, (t2){from_f<T>(gx[2 * c]), from_f<T>(gx[2 * c + 1])});
       }
 #pragma unroll
-      for (int qq = 0; qq < 2; ++qq) {
-        const t4 h4 = {from_f<T>(gy[4 * qq]), from_f<T>(gy[4 * qq + 1]), from_f<T>(gy[4 * qq + 2]), from_f<T>(gy[4 * qq + 3])};
-        const uint2 pk = __builtin_bit_cast(uint2, h4);
-        hf[2 * qq] = pk.x;
-        hf[2 * qq + 1] = pk.y;
-      }
+      for (int c = 0; c < 4; ++c) hf[c] = hw[c];
     };
     auto gelu_piece = [&](const f32x16& cur1, u32x4 (&hfc)[2], const int pc) {   // pc = 0 .. 5: A0 B0 C0 A1 B1 C1
       if (pc % 3 == 0) gelu_a(cur1, pc / 3);

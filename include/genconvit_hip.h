@@ -200,6 +200,12 @@ int gcv_k_mean_tokens(int dtype, const void* x, void* out, int nimg, int L, int 
  * (timm ConvNeXtBlock: mlp.fc1 -> GELU -> mlp.fc2 -> * gamma -> + shortcut).  w2_f32: (C,4C) fp32 device. */
 int gcv_k_fused_mlp(int dtype, int C, const void* x, const void* w1, const float* b1, const float* w2_f32,
                     const float* b2, const float* gamma, const void* resid, void* out, int M, gcv_stream s);
+/* The same launch, timed: the weights are packed once, then `iters` launches of the MLP kernel(s) alone are bracketed by
+ * HIP events on `s` (the call synchronises).  ms3[0] = average ms per MLP; for the C = 384 kernel pair ms3[1] / ms3[2] are
+ * pw1+GELU / pw2+scale+residual timed separately, else 0.  Used by profiles/microbench.py; `out` may alias `resid`. */
+int gcv_k_fused_mlp_timed(int dtype, int C, const void* x, const void* w1, const float* b1, const float* w2_f32,
+                          const float* b2, const float* gamma, const void* resid, void* out, int M, int iters,
+                          float* ms3, gcv_stream s);
 
 #if defined(GCV_BUILD)
 #pragma GCC visibility pop

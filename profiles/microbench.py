@@ -50,10 +50,13 @@ elif which.startswith("mlp"):
     w1 = (R(4 * C, C) / math.sqrt(C)).to(dt)
     w2 = R(C, 4 * C) / math.sqrt(4 * C)
     b1, b2, g = R(4 * C), R(C), R(C)
-    # pack once through the library, then time the fused kernel alone via the net-level symbol is not exported:
-    fn = lambda: _lib.check(lib.gcv_k_fused_mlp(code, C, x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
-                                                b2.data_ptr(), g.data_ptr(), res.data_ptr(), res.data_ptr(), M, st()), "mlp")
-    run(fn, 16.0 * M * C * C, 6.0 * M * C)
+    # weights packed once inside the library, the MLP kernel(s) timed alone with HIP events (gcv_k_fused_mlp_timed)
+    ms3 = (ctypes.c_float * 3)()
+    _lib.check(lib.gcv_k_fused_mlp_timed(code, C, x.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                         g.data_ptr(), res.data_ptr(), res.data_ptr(), M, iters, ms3, st()), "mlp")
+    ms = ms3[0]
+    extra = f"  (pw1 {ms3[1]*1e3:.1f} us, pw2 {ms3[2]*1e3:.1f} us)" if ms3[1] > 0 else ""
+    print(f"{which}: {ms*1e3:.1f} us/launch  {16.0*M*C*C/ms/1e9:.1f} TFLOP/s  {6.0*M*C/ms/1e6:.1f} GB/s (algorithmic){extra}")
 else:
     kind, C = which.split("_")
     C = int(C)
