@@ -26,7 +26,12 @@ static int launch_dw_roll_cfg(const T* x, const float* wdw, const float* bdw, co
   const int per_cu = std::max(1, std::min(160 * 1024 / LDS, NT > 512 ? 1 : 2));   // 116 VGPRs: 16 waves per CU
   const int slots = 256 * per_cu;
   int nb = force_bands > 0 ? force_bands : (slots + nimg - 1) / nimg;
-  nb = std::max(1, std::min(nb, std::max(1, H / 7)));
+  // ... except for launches that 7-row bands would spread over at most half the CUs (batches of 32, the 112-pixel pass):
+  // there a band's walk of rows + 6 steps at ~2 us each IS the launch time, so bands shrink to as little as two rows
+  // (8 steps instead of 13; the re-read aprons come from L2)
+  const int nb7 = std::max(1, H / 7);
+  const bool small_launch = nimg * nb7 <= 128;
+  nb = std::max(1, std::min(nb, small_launch ? std::max(1, H / 2) : nb7));
   const int band_rows = (H + nb - 1) / nb;
   const int nbands = (H + band_rows - 1) / band_rows;
   GCV_REQUIRE((int64_t)H * 7 * NS * C * (int64_t)sizeof(T) < (int64_t)1 << 31, "dwconv: one image must stay below 2 GiB");

@@ -380,24 +380,29 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) xs_pw1_kernel(const MlpPairAr
 }
 
 // ---------------------------------------------------------------------------------------------- pw2: fragment-major operands
-template <int C, int BN, int D> struct Pw2fSmem {
-  static constexpr int kStage = (8 + BN / 32) * 2048;      // 8 token blocks + BN/32 channel blocks, one 32-deep K chunk
+template <int C, int BN, int D, int TB = 8> struct Pw2fSmem {
+  static constexpr int kStage = (TB + BN / 32) * 2048;     // TB token blocks + BN/32 channel blocks, one 32-deep K chunk
   static constexpr int kBG = D * kStage;                   // b2 | gamma of the tile's BN channels
   static constexpr int bytes = kBG + 2 * BN * 4;
 };
 
-// grid = ceil(M / 256) * (C / BN); 8 waves: BN = 384 -> 2 (M) x 4 (N), wave tile 128 tokens x 96 channels;
-//                                          BN = 192 -> 4 (M) x 2 (N), wave tile  64 tokens x 96 channels
-template <typename T, int C, int BN, int D>
+// grid = ceil(M / (32 TB)) * (C / BN); 8 waves: BN = 384 -> 2 (M) x 4 (N), wave tile 128 tokens x 96 channels;
+//                                               BN = 192 -> 4 (M) x 2 (N), wave tile  64 tokens x 96 channels (TB = 8)
+// or 32 x 96 (TB = 4: 128-token tiles for launches of a few thousand tokens, where 256-token tiles leave most CUs idle and
+// every workgroup walks the whole K = 4C on its own: the vae B = 32 configuration ran 50 workgroups of 37 us each)
+template <typename T, int C, int BN, int D, int TB = 8>
 __global__ void __launch_bounds__(512, 2) pw2f_kernel(const MlpPairArgs a) {
   static_assert(sizeof(T) == 2, "16-bit storage");
   static_assert(BN == 384 || BN == 192, "tile widths");
-  typedef Pw2fSmem<C, BN, D> SM;
+  static_assert(TB == 8 || (TB == 4 && BN == 192), "token blocks per tile");
+  typedef Pw2fSmem<C, BN, D, TB> SM;
   constexpr int NKC = 4 * C / 32;                          // K chunks of 32
   constexpr int NB = BN / 32;                              // channel blocks per tile
   constexpr int CB = C / 32;                               // channel blocks in all
   constexpr int WN = BN / 96, WM = 8 / WN;                 // waves along N / M
-  constexpr int MI = 8 / WM, NI = 3;                       // token blocks / channel blocks per wave
+  constexpr int MI = TB / WM, NI = 3;                      // token blocks / channel blocks per wave
+  constexpr int HP = 2 * TB;                               // 1 KB pieces of the hidden operand per stage (8 per DMA round)
+  static_assert(HP % 8 == 0 && MI >= 1, "hidden pieces fill whole rounds of the eight waves");
   constexpr int STAGE = SM::kStage;
   constexpr int NPC = STAGE / 1024;                        // 40 / 28 pieces per stage
   constexpr int PPW = (NPC + 7) / 8;                       // 5 / 4 (BN = 192: waves 4-7 repeat the last piece)
@@ -413,25 +418,25 @@ __global__ void __launch_bounds__(512, 2) pw2f_kernel(const MlpPairArgs a) {
   const int wm = wave / WN, wn = wave % WN;
   const int ntb = (a.M + 31) >> 5;
   constexpr int NTN = C / BN;
-  const int ntiles = ((a.M + 255) >> 8) * NTN;
+  const int ntiles = ((a.M + 32 * TB - 1) / (32 * TB)) * NTN;
   const int bid = xcd_remap(blockIdx.x, ntiles);
   const int tile_m = bid / NTN, tile_n = bid - tile_m * NTN;
-  const int tb0 = tile_m * 8;
+  const int tb0 = tile_m * TB;
   const int nb0 = tile_n * NB;
 
-  // ---- per-lane DMA sources of this wave's pieces q = wave + 8 i: i < 2 are halves of hidden blocks (tb0 + q/2, kc),
-  // i >= 2 are 1 KB pieces of the NB contiguous W2 blocks (kc, nb0 ..).  (Which kind a piece is depends on i alone, so
+  // ---- per-lane DMA sources of this wave's pieces q = wave + 8 i: i < HP/8 are halves of hidden blocks (tb0 + q/2, kc),
+  // the others are 1 KB pieces of the NB contiguous W2 blocks (kc, nb0 ..).  (Which kind a piece is depends on i alone, so
   // that the per-piece state lives in named registers, not in an indexed array.)
   const unsigned char *src0, *src1, *src2, *src3, *src4 = nullptr;
   auto init_src = [&](const int i) -> const unsigned char* {
-    if (i < 2) {
+    if (i < HP / 8) {
       int tbq = tb0 + 4 * i + (wave >> 1);
       tbq = tbq < ntb ? tbq : ntb - 1;
       return (const unsigned char*)a.hidden + (int64_t)tbq * NKC * 2048 + (wave & 1) * 1024;
     }
     int q = wave + 8 * i;
     q = q < NPC ? q : NPC - 1;
-    return (const unsigned char*)a.W2f + (int64_t)nb0 * 2048 + (q - 16) * 1024;
+    return (const unsigned char*)a.W2f + (int64_t)nb0 * 2048 + (q - HP) * 1024;
   };
   // (wave-uniform bases in SGPRs; the lane's 16-byte offset is the 32-bit VGPR operand of the saddr form)
   const unsigned lane16 = (unsigned)lane * 16u;
@@ -447,7 +452,7 @@ __global__ void __launch_bounds__(512, 2) pw2f_kernel(const MlpPairArgs a) {
       q = q < NPC ? q : NPC - 1;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sp + lane16),
                                        (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
-      sp += i < 2 ? 2048 : CB * 2048;                     // next K chunk: the block after / the next row of W2 blocks
+      sp += i < HP / 8 ? 2048 : CB * 2048;                // next K chunk: the block after / the next row of W2 blocks
     }
   };
 #define GCV_P2_PIECE(I) issue_piece(std::integral_constant<int, I>{})
@@ -488,20 +493,20 @@ __global__ void __launch_bounds__(512, 2) pw2f_kernel(const MlpPairArgs a) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) hf[i] = *(const u32x4*)(st + (wm * MI + i) * 2048);
 #pragma unroll
-    for (int j = 0; j < NI; ++j) wf[0][j] = *(const u32x4*)(st + 16384 + (wn * NI + j) * 2048);
+    for (int j = 0; j < NI; ++j) wf[0][j] = *(const u32x4*)(st + TB * 2048 + (wn * NI + j) * 2048);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int sk = g >> 1;
       if (g == 0) {
 #pragma unroll
-        for (int j = 0; j < NI; ++j) wf[1][j] = *(const u32x4*)(st + 16384 + (wn * NI + j) * 2048 + 1024);
+        for (int j = 0; j < NI; ++j) wf[1][j] = *(const u32x4*)(st + TB * 2048 + (wn * NI + j) * 2048 + 1024);
       }
       if (g == 2) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) hf[i] = *(const u32x4*)(st + (wm * MI + i) * 2048 + 1024);
       }
 #pragma unroll
-      for (int i = (MI / 2) * (g & 1); i < (MI / 2) * ((g & 1) + 1); ++i)
+      for (int i = (MI * (g & 1) + 1) / 2; i < (MI * ((g & 1) + 1) + 1) / 2; ++i)   // MI = 1: all in the first group
 #pragma unroll
         for (int j = 0; j < NI; ++j)
           if (!(GCV_P2_ABLATE & 1)) Mfma<T>::run(wf[sk][j], hf[i], acc[i][j]);

@@ -24,8 +24,8 @@ template <typename T, typename S> int launch_pack_w2_frag(const S* w2, T* out, i
 static inline int xs_pw1_pick_split(int ntile, int nkc) {
   int best = 1;
   long best_cost = -1;
-  for (int ns = 1; ns <= 8; ++ns) {
-    if (nkc % ns) continue;
+  for (int ns = 1; ns <= 24; ++ns) {
+    if (nkc % ns || (nkc / ns) % 2) continue;             // whole pairs of chunks per workgroup (two per barrier)
     const long rounds = ((long)ntile * ns + 255) / 256;
     const long cost = rounds * (nkc / ns + 3);
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ns; }
@@ -66,11 +66,18 @@ template <typename T, int C> static int launch_pw2f_c(const MlpPairArgs& a, hipS
     constexpr int SMEM = Pw2fSmem<C, BN, D>::bytes;
     GCV_ENSURE_LDS((pw2f_kernel<T, C, BN, D>), SMEM);
     hipLaunchKernelGGL((pw2f_kernel<T, C, BN, D>), dim3(ntm), dim3(512), SMEM, s, a);
-  } else {
+  } else if (ntm * (C / 192) >= 128) {
     constexpr int BN = 192, D = 5;
     constexpr int SMEM = Pw2fSmem<C, BN, D>::bytes;
     GCV_ENSURE_LDS((pw2f_kernel<T, C, BN, D>), SMEM);
     hipLaunchKernelGGL((pw2f_kernel<T, C, BN, D>), dim3(ntm * (C / BN)), dim3(512), SMEM, s, a);
+  } else {
+    // a few thousand tokens (batches of 32, the 112-pixel pass): 128-token tiles, twice the workgroups, each with half the
+    // MFMAs per K chunk
+    constexpr int BN = 192, D = 6, TB = 4;
+    constexpr int SMEM = Pw2fSmem<C, BN, D, TB>::bytes;
+    GCV_ENSURE_LDS((pw2f_kernel<T, C, BN, D, TB>), SMEM);
+    hipLaunchKernelGGL((pw2f_kernel<T, C, BN, D, TB>), dim3(cdiv(a.M, 32 * TB) * (C / BN)), dim3(512), SMEM, s, a);
   }
   GCV_CHECK_HIP(hipGetLastError());
   return 0;

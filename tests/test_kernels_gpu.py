@@ -174,7 +174,10 @@ def test_stem_conv4x4_layernorm(dt, layout, res):
 
 @pytest.mark.parametrize("dt", ALL)
 @pytest.mark.parametrize("C,H,n", [(96, 56, 2), (96, 28, 3), (192, 28, 2), (192, 14, 1), (384, 14, 2), (384, 7, 3),
-                                   (768, 7, 2), (768, 3, 3)])
+                                   (768, 7, 2), (768, 3, 3),
+                                   # launches of more than 128 seven-row bands keep seven-row bands (the large-batch rule);
+                                   # the few-image cases above run the two- to four-row bands of small launches
+                                   (96, 56, 17), (384, 14, 70)])
 def test_dwconv7x7_layernorm(dt, C, H, n):
     """ConvNeXt block front half: depthwise 7x7 p3 + LayerNorm(C, eps 1e-6), NHWC."""
     dtype = DTYPES[dt]
@@ -401,7 +404,8 @@ def test_mean_over_tokens(dt):
 @pytest.mark.parametrize("C,M", [(96, 256), (96, 1000), (192, 300), (192, 37),
                                  (96, 70013),       # >= 65536 tokens at C=96: the LDS-resident persistent kernel
                                  (192, 70013),      # C=192 x-stationary kernel: 274 passes on 256 workgroups, i.e. a second pass (ring wrap-around, x reload) in some
-                                 (384, 128), (384, 1000), (384, 40000),     # C=384 kernel pair: one tile, ragged, 157 tiles (hidden range split, 256x192 pw2 tiles)
+                                 (384, 128), (384, 1000), (384, 6272),      # C=384 kernel pair, small launches: 128-token pw2 tiles, pw1 hidden range split up to 24 ways
+                                 (384, 40000),      # 157 tiles (hidden range split, 256x192 pw2 tiles)
                                  (384, 60013)])     # ... 235 token tiles: unsplit pw1, full-width 256x384 pw2 tiles, ragged last block
 def test_fused_mlp_layerscale_residual(dt, C, M):
     """timm ConvNeXtBlock tail: fc1 -> exact GELU -> fc2 -> * gamma -> + shortcut, hidden kept on chip."""
