@@ -5,6 +5,7 @@
 #include <cstdlib>
 
 #include "dwconv_roll.h"
+#include "dwconv_mfma.h"
 #include "kernels.h"
 
 namespace gcv {
@@ -41,6 +42,32 @@ static int launch_dw_roll_cfg(const T* x, const float* wdw, const float* bdw, co
   return 0;
 }
 
+// the matrix-pipe variant (dwconv_mfma.h): same grid and band rule, 12 MFMA waves + 4 staging / LayerNorm waves
+template <typename T, int C, int NS>
+static int launch_dw_mfma_cfg(const T* x, const float* wdw, const float* bdw, const float* lnw, const float* lnb, T* y,
+                              int nimg, int H, float eps, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    typedef DwMfmaLds<T, C, NS> LY;
+    constexpr int LDS = LY::bytes;
+    if (LDS > 64 * 1024) GCV_ENSURE_LDS((dwconv7_ln_mfma_kernel<T, C, NS>), LDS);
+    const int slots = 256 * std::max(1, std::min(160 * 1024 / LDS, 1));
+    int nb = (slots + nimg - 1) / nimg;
+    const int nb7 = std::max(1, H / 7);
+    const bool small_launch = nimg * nb7 <= 128;        // see launch_dw_roll_cfg
+    nb = std::max(1, std::min(nb, small_launch ? std::max(1, H / 2) : nb7));
+    const int band_rows = (H + nb - 1) / nb;
+    const int nbands = (H + band_rows - 1) / band_rows;
+    GCV_REQUIRE((int64_t)H * 7 * NS * C * (int64_t)sizeof(T) < (int64_t)1 << 31, "dwconv: one image must stay below 2 GiB");
+    hipLaunchKernelGGL((dwconv7_ln_mfma_kernel<T, C, NS>), dim3(nimg * nbands), dim3(LY::NT), LDS, s, x, wdw, bdw, lnw, lnb,
+                       y, H, band_rows, nbands, eps);
+    GCV_CHECK_HIP(hipGetLastError());
+    return 0;
+  } else {
+    set_error("dwconv7_ln_mfma: 16-bit storage only");
+    return -3;
+  }
+}
+
 // shapes covered: the whole image width (W = 7 * NS) in one workgroup of NS * C <= 768 threads
 template <typename T> bool dwconv_roll_applicable(int H, int W, int C) {
   if (W % 7 != 0 || H < 1) return false;
@@ -59,6 +86,20 @@ int launch_dwconv7_ln_roll(const T* x, const float* wdw, const float* bdw, const
                            int nimg, int H, int W, int C, float eps, hipStream_t s) {
   GCV_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) == 0, "dwconv: x / y 16-byte aligned");
   const int ns = W / 7;
+#ifndef GCV_DW_NO_MFMA
+  // 16-bit storage, 56-pixel maps at C = 96 (stage 0 of the 224-pixel passes, the largest dw launch): taps on the matrix
+  // pipe.  The same kernel is correct at C = 96 / 28 pixels and C = 192 / 28, 14 pixels (GCV_DWM_ALL builds; parity cases
+  // green) and wins there in the single-kernel microbenchmark (66 -> 56 us at 256 images), but inside the step rocprofv3
+  // shows those three 9 - 33 % SLOWER than the VALU kernel, and the whole step is the same with or without them
+  // (17.24k against 17.27k fps in paired runs), so they are not dispatched.
+#define GCV_DWM(CC, NSS) if (sizeof(T) == 2 && C == CC && ns == NSS) return launch_dw_mfma_cfg<T, CC, NSS>(x, wdw, bdw, lnw, lnb, y, nimg, H, eps, s)
+  GCV_DWM(96, 8);
+#ifdef GCV_DWM_ALL
+  GCV_DWM(96, 4);
+  GCV_DWM(192, 4); GCV_DWM(192, 2);
+#endif
+#undef GCV_DWM
+#endif
 #define GCV_ROLL(CC, NSS) if (C == CC && ns == NSS) return launch_dw_roll_cfg<T, CC, NSS>(x, wdw, bdw, lnw, lnb, y, nimg, H, eps, s)
   GCV_ROLL(96, 8); GCV_ROLL(96, 4);
   GCV_ROLL(192, 4); GCV_ROLL(192, 2);
