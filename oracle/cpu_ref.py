@@ -38,8 +38,8 @@ SWIN_HEADS = (3, 6, 12, 24)
 # "for 16-bit report the delta vs the fp32 oracle and vs a same-dtype CPU restatement".  Inside
 # ``with storage_dtype(torch.float16 | torch.bfloat16):`` the functions below round (a) the input frames, (b) every
 # weight the HIP path keeps in the storage dtype (the GEMM / conv-as-GEMM weights; biases, LayerNorm affine, layer
-# scale, depthwise taps, the first 3->16 convs, the last 16->3 transposed convs and the 500->2 layer stay fp32, as
-# in genconvit_amd/csrc/net_impl.h) and (c) every activation at the points where the HIP path stores it in HBM or
+# scale, depthwise taps (except those of the 56-pixel C = 96 maps, which are an MFMA operand: csrc/dwconv_mfma.h), the
+# first 3->16 convs, the last 16->3 transposed convs and the 500->2 layer stay fp32, as in genconvit_amd/csrc/net_impl.h) and (c) every activation at the points where the HIP path stores it in HBM or
 # feeds it to a 16-bit MFMA operand — all arithmetic stays fp32, like the kernels' accumulators.  With no storage
 # dtype set (the default) ``_q`` returns its argument untouched: the fp32 oracle is bit-for-bit what it was.
 _STORE = None
@@ -101,7 +101,10 @@ def convnext_block(sd, p, x):
     """timm 0.6.5 ConvNeXtBlock.forward: dw7x7 -> LN(NHWC)
     -> fc1 -> exact GELU -> fc2 -> * gamma -> + shortcut."""
     c = x.shape[1]
-    y = F.conv2d(x, sd[p + "conv_dw.weight"], sd[p + "conv_dw.bias"], padding=3, groups=c)
+    w_dw = sd[p + "conv_dw.weight"]
+    if c == 96 and x.shape[-1] == 56:       # the HIP path runs these taps on the matrix pipe for 16-bit storage
+        w_dw = _q(w_dw)                     # (csrc/dwconv_mfma.h): they are an MFMA operand in the storage dtype
+    y = F.conv2d(x, w_dw, sd[p + "conv_dw.bias"], padding=3, groups=c)
     y = y.permute(0, 2, 3, 1)
     y = _q(F.layer_norm(y, (c,), sd[p + "norm.weight"], sd[p + "norm.bias"], LN_EPS_CONVNEXT))
     y = F.linear(y, _q(sd[p + "mlp.fc1.weight"]), sd[p + "mlp.fc1.bias"])
