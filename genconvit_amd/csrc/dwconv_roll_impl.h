@@ -92,7 +92,11 @@ int launch_dwconv7_ln_roll(const T* x, const float* wdw, const float* bdw, const
   // green) and wins there in the single-kernel microbenchmark (66 -> 56 us at 256 images), but inside the step rocprofv3
   // shows those three 9 - 33 % SLOWER than the VALU kernel, and the whole step is the same with or without them
   // (17.24k against 17.27k fps in paired runs), so they are not dispatched.
-#define GCV_DWM(CC, NSS) if (sizeof(T) == 2 && C == CC && ns == NSS) return launch_dw_mfma_cfg<T, CC, NSS>(x, wdw, bdw, lnw, lnb, y, nimg, H, eps, s)
+  // Only launches whose bands are at least 14 rows long (batches of 64 images and more at this size): a workgroup of the
+  // matrix-pipe kernel first zeroes its ring and builds 42 tap-operand registers per lane from 84 global loads, which a
+  // 7-row band does not pay back (vae B = 32 bf16, paired runs: 19.3k fps with it, 19.9k with the VALU kernel there).
+  const bool long_bands = (int64_t)nimg * H >= 14 * 256;
+#define GCV_DWM(CC, NSS) if (sizeof(T) == 2 && C == CC && ns == NSS && long_bands) return launch_dw_mfma_cfg<T, CC, NSS>(x, wdw, bdw, lnw, lnb, y, nimg, H, eps, s)
   GCV_DWM(96, 8);
 #ifdef GCV_DWM_ALL
   GCV_DWM(96, 4);

@@ -177,7 +177,10 @@ def test_stem_conv4x4_layernorm(dt, layout, res):
                                    (768, 7, 2), (768, 3, 3),
                                    # launches of more than 128 seven-row bands keep seven-row bands (the large-batch rule);
                                    # the few-image cases above run the two- to four-row bands of small launches
-                                   (96, 56, 17), (384, 14, 70)])
+                                   (96, 56, 17), (384, 14, 70),
+                                   # 16-bit storage, 56-pixel C = 96 maps in bands of 14 rows and more: the matrix-pipe kernel
+                                   # (dwconv_mfma.h; fp32 storage stays on the VALU kernel): four 14-row bands, ragged 19/19/18
+                                   (96, 56, 64), (96, 56, 100)])
 def test_dwconv7x7_layernorm(dt, C, H, n):
     """ConvNeXt block front half: depthwise 7x7 p3 + LayerNorm(C, eps 1e-6), NHWC."""
     dtype = DTYPES[dt]
