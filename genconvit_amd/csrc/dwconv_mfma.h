@@ -17,12 +17,21 @@
 // 128 MAC / cycle / SIMD against 16 - 27 for v_fma_f32), so a row of 56 pixels x 96 channels is 504 MFMAs = 1008 cycles
 // per SIMD where the VALU kernel spends ~3100 cycles on FMAs alone.
 //
-// Operands.  The input ring stays NHWC but 16-bit (the staging waves copy 16-byte pieces, no widening), with a pixel
-// pitch of 2 C + 16 bytes: a lane gathers the four x' of its B operand with four ds_read_u16 (immediate offsets k * pitch)
-// and two v_lshl_or_b32, and the padded pitch puts the four x blocks of a wave's lanes on different banks.  Walking DOWN
-// the band, an input row is read ONCE and feeds the seven output rows that are still open (seven accumulator sets per
-// task, rotated at compile time like dwconv_roll.h's): 12 gathers for 42 MFMAs.  Taps are rounded to the storage dtype (they
-// are an MFMA operand); accumulation, bias and LayerNorm are fp32 as before.  fp32 storage keeps dwconv_roll.h.
+// Operands.  The input ring stays NHWC but 16-bit (the staging waves copy 16-byte pieces as two 8-byte LDS writes, no
+// widening), with a pixel pitch of 2 C + 8 bytes: a lane gathers the four x' of a B operand with four ds_read_b32 (immediate
+// offsets k * pitch; two neighbouring channels share a dword) and two v_perm_b32, and the pitch puts the four x blocks of a
+// half wave on different banks.  Walking DOWN the band, an input row is read ONCE and feeds the seven output rows that are
+// still open (seven accumulator sets per task, rotated at compile time like dwconv_roll.h's): 12 gathers for 42 MFMAs per
+// wave and row, task 0's operands of the NEXT row fetched under task 1's MFMAs (with every wave gathering right behind
+// the barrier the matrix pipe idled for the 1100+ cycles the 288 LDS reads of a step take).  Taps are rounded to the storage
+// dtype (they are an MFMA operand); accumulation, bias and LayerNorm are fp32 as before.  fp32 storage keeps dwconv_roll.h.
+//
+// Measured (profiles/r03_micro/dw_mfma_measurements.txt): 144 -> 108 us at 256 images in
+// the single-kernel loop, 85 -> 80 us per launch inside the step, + 1 % whole-step throughput.  A workgroup's set-up (ring
+// zeroing, 84 tap loads per lane) is only paid back by bands of 14 rows and more: the launcher keeps shorter bands (batches
+// of 32) on the VALU kernel.  Registers are the limit: 42 tap operands + 56 accumulators + 12 gathered operands leave no
+// slack under the 128 of a 16-wave workgroup (a straight-line interior path spilled 220), and C = 384 would need 84 tap
+// operands per wave.
 #pragma once
 #include "dwconv_roll.h"
 
