@@ -38,6 +38,11 @@ from genconvit_amd.model.genconvit import GenConViT                 # noqa: E402
 from genconvit_amd.model.genconvit_ed import GenConViTED            # noqa: E402
 from genconvit_amd.model.genconvit_vae import GenConViTVAE          # noqa: E402
 
+# What the matrix pipe sustains with DATA in the operands, measured on this pool (profiles/micro/mfma_shape_clock.hip: the
+# x-stationary MLP inner loop, LDS fragment reads + v_mfma_f32_32x32x16 only, random fp16 operands: 1.38 PFLOP/s at an in-kernel
+# clock of 1.47 GHz; 2.08 PFLOP/s at 2.36 GHz on zeros).  Reported beside `peak` for 16-bit runs, never instead of it.
+SUSTAINED_MFMA_RANDOM = {"value": 1382.0, "unit": "TFLOP/s", "in_kernel_clock_ghz": 1.47,
+                         "source": "profiles/r03_micro/mfma_shape_clock.txt"}
 PEAK = {  # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks, HBM3E spec
     "mfma": {"f32": 157.3, "f16": 2500.0, "bf16": 2500.0},   # TFLOP/s
     "hbm": 8000.0,                                             # GB/s
@@ -271,11 +276,15 @@ def main():
                 peak, unit = PEAK["hbm"], "GB/s"
             lps = d["launches"] // max(a.profile_steps, 1)
             traffic, traffic_src = measured_traffic(tkey, a.net, a.batch, a.dtype, lps) if tkey else (None, None)
-            return {"kernel": name, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
-                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
-                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
-                    "launches_per_step": d["launches"] // max(a.profile_steps, 1), "avg_launch_ms": round(avg_ms, 4),
-                    "share_of_step": round(d["ms"] / total_ms, 3)}
+            e = {"kernel": name, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+                 "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+                 "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(d["bytes"] / d["launches"]),
+                 "launches_per_step": d["launches"] // max(a.profile_steps, 1), "avg_launch_ms": round(avg_ms, 4),
+                 "share_of_step": round(d["ms"] / total_ms, 3)}
+            if bound == "mfma" and a.dtype in ("f16", "bf16"):
+                e["peak_sustained_random_operands"] = dict(SUSTAINED_MFMA_RANDOM,
+                                                           frac=round(achieved / SUSTAINED_MFMA_RANDOM["value"], 4))
+            return e
         mfma_name = "mfma_gemm(cnx.pw1_gelu+cnx.pw2_scale_res+cnx.fused_mlp)"
         name, d = max(fam.items(), key=lambda kv: kv[1]["ms"])
         bound = "mfma" if name.startswith("mfma_gemm") or "gemm" in name else "hbm"
