@@ -44,7 +44,22 @@ def _c_comm(group, device):
         else:
             box = [_lib.Comm.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            _COMMS[key] = _lib.Comm(world, rank, box[0], device.index if device.index is not None else torch.cuda.current_device())
+            # ncclCommInitRank through the C ABI; if it fails on ANY rank (agreed over the torch group again), every rank
+            # drops its communicator and the gather stays on torch.distributed's own RCCL communicator
+            try:
+                c = _lib.Comm(world, rank, box[0], device.index if device.index is not None else torch.cuda.current_device())
+                ok, why = 1, ""
+            except Exception as e:
+                c, ok, why = None, 0, str(e)
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 0:
+                if not ok:
+                    print(f"[genconvit_amd.dist] rank {rank}: gcv_comm_create failed ({why}); using torch.distributed", flush=True)
+                if c is not None:
+                    c.close()
+                c = None
+            _COMMS[key] = c
     return _COMMS[key]
 
 
