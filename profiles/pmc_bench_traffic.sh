@@ -47,10 +47,10 @@ for k in set(fe) | set(wr):
     f["read_bytes"] += 2.0 * fe[k][1] * 1024.0
     f["write_bytes"] += wr[k][1] * 1024.0
     f["kernels"].append(k)
-# the bench line of the FETCH pass says how many launches per step each family has: 4 forward steps were recorded
-# (1 warm-up + 2 timed + 1 profiled), so dispatches must be exactly 4 x launches_per_step — anything else means the
+# the bench line of the FETCH pass says how many launches per step each family has: 5 forward steps were recorded
+# (1 warm-up + 2 timed + 1 untimed profiled + 1 profiled), so dispatches must be exactly 4 x launches_per_step — anything else means the
 # classification above and bench.py's tags have drifted apart, and the file would mislead
-STEPS = 4
+STEPS = 5
 line = None
 for ln in open(out + "/fetch.log"):
     ln = ln.strip()
@@ -80,6 +80,6 @@ for key, f in res.items():
     f["kernels"] = sorted(set(f["kernels"]))
 if not res: sys.exit("no *counter_collection.csv found under " + out)
 json.dump({"config": {"net": cfg.net, "batch": cfg.batch, "dtype": cfg.dtype}, "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `bench.py --steps 2 --warmup 1 --profile-steps 1` "
-                   "(4 forward steps), FETCH_SIZE x2 per the gfx950 correction; dispatches checked against bench.py's launches_per_step", "families": res}, open(out + "/traffic.json", "w"), indent=1)
+                   "(5 forward steps), FETCH_SIZE x2 per the gfx950 correction; dispatches checked against bench.py's launches_per_step", "families": res}, open(out + "/traffic.json", "w"), indent=1)
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "kernels"} for k, v in res.items()}, indent=1))
 PY
