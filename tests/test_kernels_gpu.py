@@ -98,7 +98,8 @@ def test_gemm_splitk(dt, M, N, K, splitk, kps):
 
 # ----------------------------------------------------------------------------- conv as GEMM
 @pytest.mark.parametrize("dt", ALL)
-@pytest.mark.parametrize("n,H,cin,cout", [(2, 16, 16, 32), (3, 8, 32, 64), (2, 14, 128, 256), (1, 28, 64, 128)])
+@pytest.mark.parametrize("n,H,cin,cout", [(2, 16, 16, 32), (3, 8, 32, 64), (2, 14, 128, 256), (1, 28, 64, 128),
+                                          (3, 112, 16, 32)])     # 37632 rows: 294 tiles (256-row tiles were tried for such launches: 99 vs 79 us at B=128)
 def test_conv3x3_relu_maxpool(dt, n, H, cin, cout):
     """ED encoder layers 2-5 (model/genconvit_ed.py:18-32): conv3x3 s1 p1 -> ReLU -> maxpool2."""
     dtype = DTYPES[dt]
