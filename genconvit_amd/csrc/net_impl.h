@@ -572,15 +572,23 @@ template <typename T> struct NetImpl : NetBase {
       if (i > 0) {
         const int Cp = kDims[i - 1];
         int64_t newM = 0, noff[4];
-        for (int s = 0; s < nseg; ++s) {
-          noff[s] = newM;
-          const int nh = h[s] / 2, nw = wd[s] / 2;
-          GCV_REQUIRE(nh > 0 && nw > 0, "image too small for ConvNeXt downsampling");
-          GCV_TRY(run("cnx.ln_patchify", 8.0 * m[s] * Cp, 2.0 * sizeof(T) * (double)m[s] * Cp, [&] {
+        for (int s = 0; s < nseg;) {
+          // neighbouring segments of one geometry (ED: reconstruction + original pass) are contiguous on both sides:
+          // one launch over all their images, as for the depthwise kernel below
+          int e = s, nimg = 0;
+          int64_t mm = 0;
+          const int64_t noff0 = newM;
+          while (e < nseg && h[e] == h[s] && wd[e] == wd[s]) {
+            noff[e] = newM;
+            GCV_REQUIRE(h[e] / 2 > 0 && wd[e] / 2 > 0, "image too small for ConvNeXt downsampling");
+            newM += (int64_t)segs[e].n * (h[e] / 2) * (wd[e] / 2);
+            nimg += segs[e].n; mm += m[e]; ++e;
+          }
+          GCV_TRY(run("cnx.ln_patchify", 8.0 * mm * Cp, 2.0 * sizeof(T) * (double)mm * Cp, [&] {
             return launch_ln_patchify<T>(X + moff[s] * Cp, w.down[i - 1].ln_w, w.down[i - 1].ln_b,
-                                         Y + noff[s] * 4 * Cp, segs[s].n, h[s], wd[s], Cp, 1e-6f, cur);
+                                         Y + noff0 * 4 * Cp, nimg, h[s], wd[s], Cp, 1e-6f, cur);
           }));
-          newM += (int64_t)segs[s].n * nh * nw;
+          s = e;
         }
         for (int s = 0; s < nseg; ++s) {
           h[s] /= 2;
