@@ -652,11 +652,17 @@ template <typename T> struct NetImpl : NetBase {
     }
     int no = 0;
     for (int s = 0; s < nseg; ++s) {
-      const int HW = h[s] * wd[s];
-      GCV_TRY(run("cnx.pool_ln", 2.0 * m[s] * 768, sizeof(T) * (double)m[s] * 768, [&] {
-        return launch_pool_ln<T>(X + moff[s] * 768, w.head_lnw, w.head_lnb, Pool + (int64_t)no * 768, segs[s].n, HW,
-                                 768, 1e-6f, cur);
-      }));
+      // pooling + LayerNorm: one launch over neighbouring segments of one map size (their tokens and their pooled rows are
+      // contiguous); the classifier GEMM stays per segment (each writes its own column block of the feature matrix)
+      if (s == 0 || h[s] * wd[s] != h[s - 1] * wd[s - 1]) {
+        int e = s, nimg = 0;
+        int64_t mm = 0;
+        while (e < nseg && h[e] * wd[e] == h[s] * wd[s]) { nimg += segs[e].n; mm += m[e]; ++e; }
+        GCV_TRY(run("cnx.pool_ln", 2.0 * mm * 768, sizeof(T) * (double)mm * 768, [&] {
+          return launch_pool_ln<T>(X + moff[s] * 768, w.head_lnw, w.head_lnb, Pool + (int64_t)no * 768, nimg, h[s] * wd[s],
+                                   768, 1e-6f, cur);
+        }));
+      }
       GemmArgs g{};
       g.A = Pool + (int64_t)no * 768; g.lda = 768; g.Wt = w.head_fc_w; g.C = segs[s].out; g.ldc = segs[s].out_ld;
       g.bias = w.head_fc_b; g.M = segs[s].n; g.N = 1000; g.K = 768; g.act = segs[s].act; g.splitk = 1;
