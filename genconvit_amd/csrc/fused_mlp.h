@@ -52,9 +52,24 @@ struct MlpArgs {
   const void* resid;   // (M, C) block input (may alias out)
   void* out;           // (M, C)
   int M;
+  // Optional (fused_mlp_res_kernel only; the LAST block of stage 0): the stage boundary's LayerNorm2d + 2x2 space-to-depth
+  // (timm ConvNeXt `downsample`: LayerNorm2d -> Conv2d(k=2, s=2)) applied to the output rows, which are needed by
+  // nothing else: `out` is then the patchified (M/4, 4C) operand of the down-sampling GEMM and the (M, C) residual stream is
+  // not written at all.  Tokens [tok0[s], tok0[s+1]) are images of hw[s] = H*W pixels, W = w[s]; their patch rows start
+  // at out0[s].
+  const float* lnp_w = nullptr;
+  const float* lnp_b = nullptr;
+  float lnp_eps = 0.0f;
+  int lnp_nseg = 0;
+  int lnp_tok0[4] = {0, 0, 0, 0};
+  int lnp_hw[4] = {1, 1, 1, 1};
+  int lnp_wd[4] = {1, 1, 1, 1};
+  int lnp_out0[4] = {0, 0, 0, 0};
 };
 
 constexpr int kMlpHC = 96;
+// whether launch_fused_mlp runs the LDS-resident kernel (fused_mlp_res.h: the only one with the LN-patchify epilogue)
+static inline bool fused_mlp_res_applies(int C, int64_t M) { return C == 96 && M >= 256 * 8 * 32; }
 
 template <typename T, int C, int NW> struct MlpSmem {
   static constexpr int kRow1 = C * (int)sizeof(T) + 16;          // W1 chunk row (C elements) + pad

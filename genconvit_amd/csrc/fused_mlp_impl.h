@@ -63,7 +63,13 @@ template <typename T> int launch_fused_mlp_res(const MlpArgs& a, hipStream_t s) 
   static const int nw = [] { const char* e = exp_env("GCV_MLP_RES_WAVES"); return e ? std::atoi(e) : 8; }();
   const int wave_tiles = cdiv(a.M, 32);
   const int nwg = cdiv(wave_tiles, nw) < 256 ? cdiv(wave_tiles, nw) : 256;    // one persistent workgroup per CU
-  hipLaunchKernelGGL((fused_mlp_res_kernel<T>), dim3(nwg), dim3(64 * nw), SMEM, s, a);
+  if (a.lnp_nseg > 0) {                                    // last block of the stage: LayerNorm2d + space-to-depth epilogue
+    GCV_REQUIRE(a.lnp_w && a.lnp_b && a.lnp_nseg <= 4, "fused MLP: LN-patchify epilogue arguments");
+    GCV_ENSURE_LDS((fused_mlp_res_kernel<T, true>), SMEM);
+    hipLaunchKernelGGL((fused_mlp_res_kernel<T, true>), dim3(nwg), dim3(64 * nw), SMEM, s, a);
+  } else {
+    hipLaunchKernelGGL((fused_mlp_res_kernel<T>), dim3(nwg), dim3(64 * nw), SMEM, s, a);
+  }
   GCV_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -94,7 +100,8 @@ template <typename T> int launch_fused_mlp(const MlpArgs& a, int C, hipStream_t 
   // prologue / epilogue); C=192: the double-buffered chunks fill the LDS, one 8-wave workgroup per CU
   // C=96 with enough tokens to give every wave of the chip several tiles: weights resident in LDS, no barriers
   static const int res_mode = [] { const char* e = exp_env("GCV_MLP_RESIDENT"); return e ? std::atoi(e) : 1; }();
-  if (C == 96 && res_mode && a.M >= 256 * 8 * 32) return launch_fused_mlp_res<T>(a, s);
+  if (res_mode && fused_mlp_res_applies(C, a.M)) return launch_fused_mlp_res<T>(a, s);
+  GCV_REQUIRE(a.lnp_nseg == 0, "fused MLP: the LN-patchify epilogue exists in the LDS-resident kernel only");
   if (C == 96) return launch_mlp_c<T, 96, 4>(a, s);
 #ifdef GCV_EXPERIMENTS
   if (mlp_use_ring(C)) return launch_fused_mlp_ring<T>(a, C, s);

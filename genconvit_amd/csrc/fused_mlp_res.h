@@ -29,12 +29,17 @@ struct MlpResSmem {
   static constexpr int kB2 = kB1 + 384 * 4;              // 96 floats
   static constexpr int kG = kB2 + 96 * 4;                // 96 floats
   static constexpr int kCtr = kG + 96 * 4;               // tile counter of the workgroup (one dword)
-  static constexpr int bytes = kCtr + 16;                // 149776
+  static constexpr int kLn = kCtr + 16;                  // LNP variant: LayerNorm weight | bias of the stage boundary (2 x 96 floats)
+  static constexpr int bytes = kLn + 2 * 96 * 4;         // 150544
 };
 
 __device__ __forceinline__ int mlp_res_swz(int row, int k16) { return (k16 & ~3) | ((k16 & 3) ^ ((row >> 2) & 3)); }
 
-template <typename T>
+// LNP: the epilogue applies the stage boundary's LayerNorm2d + 2x2 space-to-depth instead of storing the residual stream
+// (MlpArgs::lnp_*): a wave owns whole token rows (lanes l and l + 32 hold the two halves of a row's 96 channels), so the
+// statistics are 96 register operations and one cross-lane exchange, and LN-patchify's pass over the tensor (77 MB read +
+// 77 MB written per 128 images) disappears together with this kernel's own 77 MB store.
+template <typename T, bool LNP = false>
 __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) {
   static_assert(sizeof(T) == 2, "fused MLP is built for 16-bit storage");
   constexpr int C = 96, HC = 96, NG = 12;                 // 12 hidden groups of 32
@@ -73,6 +78,10 @@ __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) 
     for (int i = tid; i < 384 + 96 + 96; i += (int)blockDim.x)
       sf[i] = i < 384 ? a.b1[i] : (i < 480 ? a.b2[i - 384] : a.gamma[i - 480]);
     if (tid == 0) *reinterpret_cast<int*>(smem + MlpResSmem::kCtr) = (int)blockDim.x >> 6;   // slots 0 .. nwaves-1 are taken
+    if (LNP) {
+      float* sl = reinterpret_cast<float*>(smem + MlpResSmem::kLn);
+      for (int i = tid; i < 192; i += (int)blockDim.x) sl[i] = i < 96 ? a.lnp_w[i] : a.lnp_b[i - 96];
+    }
   }
   __syncthreads();
   RES_STAMP(11);
@@ -258,6 +267,71 @@ __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) 
     // One v_permlane32_swap per dword of a (q, q+1) pair leaves lanes 0-31 with the 16 contiguous bytes of piece q
     // and lanes 32-63 with those of piece q+1: six 16-byte stores per tile instead of twelve 8-byte ones (each store
     // instruction touches 32 rows; the epilogue was 5.6k of a tile's 26k cycles, bound by store issue).
+    if constexpr (LNP) {
+      // ---- out = LayerNorm2d(resid + gamma * (acc2 + b2)) at the patch position of token m
+      // the residual rows first (same permlane32 exchange as below), in place of the accumulators
+      float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+      for (int o = 0; o < NO; ++o)
+#pragma unroll
+        for (int q = 0; q < 4; q += 2) {
+          const u32x4 rw = rres[o][q >> 1];
+          const auto rx = __builtin_amdgcn_permlane32_swap(rw[0], rw[2], false, false);
+          const auto ry = __builtin_amdgcn_permlane32_swap(rw[1], rw[3], false, false);
+          const t4 rr[2] = {__builtin_bit_cast(t4, uint2{rx[0], ry[0]}), __builtin_bit_cast(t4, uint2{rx[1], ry[1]})};
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const int n = 32 * o + 8 * (q + d) + 4 * lh;
+            const f32x4 bv = *(const f32x4*)(sB2t + n);
+            const f32x4 gv = *(const f32x4*)(sGt + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float v = fmaf(acc2[o][4 * (q + d) + e] + bv[e], gv[e], to_f(rr[d][e]));
+              acc2[o][4 * (q + d) + e] = v;
+              s1 += v;
+              s2 = fmaf(v, v, s2);
+            }
+          }
+        }
+      s1 += __shfl_xor(s1, 32);                            // the other half of the row's channels lives in lane ^ 32
+      s2 += __shfl_xor(s2, 32);
+      const float mean = s1 * (1.0f / C);
+      const float rstd = __builtin_amdgcn_rsqf(fmaxf(fmaf(-mean, mean, s2 * (1.0f / C)), 0.0f) + a.lnp_eps);
+      const float nmr = -mean * rstd;
+      // patch position of this lane's token: segment, image, (y, x) -> patch row and the quarter of its 4C columns
+      int sg = 0;
+#pragma unroll
+      for (int t = 1; t < 4; ++t) sg += (t < a.lnp_nseg && (int)mc >= a.lnp_tok0[t]) ? 1 : 0;
+      const int local = (int)mc - a.lnp_tok0[sg];
+      const int hw = a.lnp_hw[sg], wd = a.lnp_wd[sg];
+      const int img = local / hw, rem = local - img * hw;
+      const int py = rem / wd, px = rem - py * wd;
+      const int64_t prow = (int64_t)a.lnp_out0[sg] + ((int64_t)img * (hw / wd / 2) + (py >> 1)) * (wd >> 1) + (px >> 1);
+      T* const dst = Op + prow * (4 * C) + ((py & 1) * 2 + (px & 1)) * C;
+      const float* sLw = reinterpret_cast<const float*>(smem + MlpResSmem::kLn);
+      asm volatile("" : "+v"(sLw));
+#pragma unroll
+      for (int o = 0; o < NO; ++o)
+#pragma unroll
+        for (int q = 0; q < 4; q += 2) {
+          uint2 pk[2];
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const int n = 32 * o + 8 * (q + d) + 4 * lh;
+            const f32x4 wv = *(const f32x4*)(sLw + n);
+            const f32x4 cv = *(const f32x4*)(sLw + 96 + n);
+            t4 o4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o4[e] = from_f<T>(fmaf(fmaf(acc2[o][4 * (q + d) + e], rstd, nmr), wv[e], cv[e]));
+            pk[d] = __builtin_bit_cast(uint2, o4);
+          }
+          auto sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+          auto sy = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+          const u32x4 w = {sx[0], sy[0], sx[1], sy[1]};
+          const int n16 = 32 * o + 8 * q + 8 * lh;
+          if (m < a.M) *(u32x4*)(dst + n16) = w;
+        }
+    } else
 #pragma unroll
     for (int o = 0; o < NO; ++o)
 #pragma unroll

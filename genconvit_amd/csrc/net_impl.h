@@ -157,6 +157,11 @@ template <typename T> struct NetImpl : NetBase {
   bool use_fused_mlp = exp_env("GCV_NO_FUSED_MLP") == nullptr;   // A/B switches for profiling
   // (GCV_EXPERIMENTS builds only, see common.h exp_env: the round-2 kernels behind their old switches)
   bool use_fused_mlp384 = exp_env("GCV_FUSED_MLP384") != nullptr;
+#ifdef GCV_NO_LNP_EPILOGUE
+  bool use_lnp_epilogue = false;                         // A/B builds: LayerNorm-patchify as its own launch everywhere
+#else
+  bool use_lnp_epilogue = true;
+#endif
   bool use_mlp_pair = exp_env("GCV_NO_MLP_PAIR") == nullptr;     // C = 384: pw1 / pw2 kernel pair (mlp_pair.h)
   bool use_xs_mlp = exp_env("GCV_MLP_LEGACY") == nullptr;        // C = 192: x-stationary fused MLP (xs_mlp.h)
   // Schedule of vae_forward.  SPLIT: backbone(x) — which depends on nothing but the input — runs on a side stream while
@@ -567,6 +572,7 @@ template <typename T> struct NetImpl : NetBase {
       }));
     }
     int bi = 0;
+    bool lnp_fused = false;       // the previous stage's last MLP has already written the LayerNorm'ed patches (into Hd)
     for (int i = 0; i < 4; ++i) {
       const int C = kDims[i];
       if (i > 0) {
@@ -584,10 +590,11 @@ template <typename T> struct NetImpl : NetBase {
             newM += (int64_t)segs[e].n * (h[e] / 2) * (wd[e] / 2);
             nimg += segs[e].n; mm += m[e]; ++e;
           }
-          GCV_TRY(run("cnx.ln_patchify", 8.0 * mm * Cp, 2.0 * sizeof(T) * (double)mm * Cp, [&] {
-            return launch_ln_patchify<T>(X + moff[s] * Cp, w.down[i - 1].ln_w, w.down[i - 1].ln_b,
-                                         Y + noff0 * 4 * Cp, nimg, h[s], wd[s], Cp, 1e-6f, cur);
-          }));
+          if (!lnp_fused)
+            GCV_TRY(run("cnx.ln_patchify", 8.0 * mm * Cp, 2.0 * sizeof(T) * (double)mm * Cp, [&] {
+              return launch_ln_patchify<T>(X + moff[s] * Cp, w.down[i - 1].ln_w, w.down[i - 1].ln_b,
+                                           Y + noff0 * 4 * Cp, nimg, h[s], wd[s], Cp, 1e-6f, cur);
+            }));
           s = e;
         }
         for (int s = 0; s < nseg; ++s) {
@@ -598,7 +605,8 @@ template <typename T> struct NetImpl : NetBase {
         }
         M = newM;
         GemmArgs g{};
-        g.A = Y; g.lda = 4 * Cp; g.Wt = w.down[i - 1].w; g.C = X; g.ldc = C; g.bias = w.down[i - 1].b;
+        g.A = lnp_fused ? Hd : Y; g.lda = 4 * Cp; g.Wt = w.down[i - 1].w; g.C = X; g.ldc = C; g.bias = w.down[i - 1].b;
+        lnp_fused = false;
         g.M = (int)M; g.N = C; g.K = 4 * Cp; g.act = ACT_NONE; g.splitk = 1;
         GCV_TRY(gemm("cnx.down_gemm", g, A_PLAIN, EPI_BIAS_ACT));
       }
@@ -625,6 +633,22 @@ template <typename T> struct NetImpl : NetBase {
           }
           if (k.fc2_wc && use_fused_mlp && (C < 384 || use_fused_mlp384)) {
             MlpArgs ma{Y, k.fc1_w, k.fc1_b, k.fc2_wc, k.fc2_b, k.gamma, X, X, (int)M};
+            // last block of the stage on the LDS-resident kernel: its epilogue applies the stage boundary's LayerNorm2d +
+            // space-to-depth and writes the down-sampling GEMM's operand (into Hd: Y is still being read as x_ln); the
+            // residual stream ends here and is not written
+            if (j == kDepths[i] - 1 && i < 3 && use_lnp_epilogue && fused_mlp_res_applies(C, M)) {
+              ma.out = Hd;
+              ma.lnp_w = w.down[i].ln_w; ma.lnp_b = w.down[i].ln_b; ma.lnp_eps = 1e-6f; ma.lnp_nseg = nseg;
+              int64_t o0 = 0;
+              bool even = true;
+              for (int s = 0; s < nseg; ++s) {
+                ma.lnp_tok0[s] = (int)moff[s]; ma.lnp_hw[s] = h[s] * wd[s]; ma.lnp_wd[s] = wd[s]; ma.lnp_out0[s] = (int)o0;
+                o0 += (int64_t)segs[s].n * (h[s] / 2) * (wd[s] / 2);
+                even = even && h[s] % 2 == 0 && wd[s] % 2 == 0;
+              }
+              if (even) lnp_fused = true;
+              else { ma.out = X; ma.lnp_nseg = 0; }     // odd maps drop their last row / column: the separate kernel does that
+            }
             GCV_TRY(run("cnx.fused_mlp", 16.0 * M * C * (double)C, 3.0 * sizeof(T) * (double)M * C + 16.0 * C * C,
                         [&] { return launch_fused_mlp<T>(ma, C, cur); }));
             continue;
