@@ -627,6 +627,19 @@ template <typename T> struct NetImpl : NetBase {
         if constexpr (sizeof(T) == 2) {
           if (k.fc_wp) {
             XsMlpArgs xa{Y, k.fc_wp, k.fc1_b, k.fc2_b, k.gamma, X, X, (int)M};
+            if (j == kDepths[i] - 1 && i < 3 && use_lnp_epilogue) {   // stage boundary in the epilogue (see the C = 96 case below)
+              bool even = true;
+              int64_t o0 = 0;
+              for (int s = 0; s < nseg; ++s) {
+                xa.lnp_tok0[s] = (int)moff[s]; xa.lnp_hw[s] = h[s] * wd[s]; xa.lnp_wd[s] = wd[s]; xa.lnp_out0[s] = (int)o0;
+                o0 += (int64_t)segs[s].n * (h[s] / 2) * (wd[s] / 2);
+                even = even && h[s] % 2 == 0 && wd[s] % 2 == 0;
+              }
+              if (even) {
+                xa.out = Hd; xa.lnp_w = w.down[i].ln_w; xa.lnp_b = w.down[i].ln_b; xa.lnp_eps = 1e-6f; xa.lnp_nseg = nseg;
+                lnp_fused = true;
+              }
+            }
             GCV_TRY(run("cnx.fused_mlp", 16.0 * M * C * (double)C, 3.0 * sizeof(T) * (double)M * C + 16.0 * C * C,
                         [&] { return launch_xs_mlp<T>(xa, C, cur); }));
             continue;

@@ -38,6 +38,16 @@ struct XsMlpArgs {
   const void* resid;    // (M, C) block input (may alias out)
   void* out;            // (M, C)
   int M;
+  // Optional (last block of a stage): the stage boundary's LayerNorm2d + 2x2 space-to-depth in the epilogue, as in
+  // MlpArgs (fused_mlp.h): `out` is then the patchified (M/4, 4C) operand of the down-sampling GEMM
+  const float* lnp_w = nullptr;
+  const float* lnp_b = nullptr;
+  float lnp_eps = 0.0f;
+  int lnp_nseg = 0;
+  int lnp_tok0[4] = {0, 0, 0, 0};
+  int lnp_hw[4] = {1, 1, 1, 1};
+  int lnp_wd[4] = {1, 1, 1, 1};
+  int lnp_out0[4] = {0, 0, 0, 0};
 };
 
 // W1 (4C, C) and W2 (C, 4C) row-major of type S on the device -> records of T.  Fragment f of a record is 512 elements
@@ -73,7 +83,8 @@ template <int C> struct XsMlpCfg {
   static constexpr int NLW = NM / PPW;                                  // loader waves: 4 / 8
   static constexpr int kB1 = D * REC;                                   // b1 (4C floats)
   static constexpr int kBG = kB1 + 4 * C * 4;                           // b2 | gamma (2C floats)
-  static constexpr int bytes = kBG + 2 * C * 4;
+  static constexpr int kLn = kBG + 2 * C * 4;                           // LNP variant: LayerNorm weight | bias (2C floats)
+  static constexpr int bytes = kLn + 2 * C * 4;
   static constexpr int NSB = NM / 4;                                    // sub-blocks of four MFMAs per step: 3 / 6
 };
 
@@ -99,7 +110,7 @@ __device__ unsigned long long gcv_xm_stamps[64 * 64];
 
 #define GCV_XM_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory")
 
-template <typename T, int C>
+template <typename T, int C, bool LNP = false>
 __global__ void __launch_bounds__(512, 2) xs_mlp_kernel(const XsMlpArgs a, const int npass) {
   static_assert(sizeof(T) == 2, "16-bit storage");
   static_assert(C == 96 || C == 192, "narrow ConvNeXt stages");
@@ -127,6 +138,10 @@ __global__ void __launch_bounds__(512, 2) xs_mlp_kernel(const XsMlpArgs a, const
   {
     float* sf = reinterpret_cast<float*>(smem + CF::kB1);
     for (int i = tid; i < 6 * C; i += 512) sf[i] = i < 4 * C ? a.b1[i] : (i < 5 * C ? a.b2[i - 4 * C] : a.gamma[i - 5 * C]);
+    if (LNP) {
+      float* sl = reinterpret_cast<float*>(smem + CF::kLn);
+      for (int i = tid; i < 2 * C; i += 512) sl[i] = i < C ? a.lnp_w[i] : a.lnp_b[i - C];
+    }
   }
   __syncthreads();
 
@@ -320,6 +335,70 @@ __global__ void __launch_bounds__(512, 2) xs_mlp_kernel(const XsMlpArgs a, const
       const float* sB2 = sB2_;
       const float* sG = sG_;
       asm volatile("" : "+v"(sB2), "+v"(sG));              // keeps the LDS reads inside the pass loop, unspilled
+      if constexpr (LNP) {
+        // out = LayerNorm2d(resid + gamma * (acc2 + b2)) at the patch position of token m (see fused_mlp_res.h)
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int o = 0; o < NO; ++o)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const u32x4 rw = rres[2 * o + pr];
+            const auto rx = __builtin_amdgcn_permlane32_swap(rw[0], rw[2], false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(rw[1], rw[3], false, false);
+            const t4 rq[2] = {__builtin_bit_cast(t4, uint2{rx[0], ry[0]}), __builtin_bit_cast(t4, uint2{rx[1], ry[1]})};
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+              const int q = 2 * pr + d;
+              const int n = 32 * o + 8 * q + 4 * lh;
+              const f32x4 bv = *(const f32x4*)(sB2 + n);
+              const f32x4 gv = *(const f32x4*)(sG + n);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float v = fmaf(acc2[o][4 * q + e] + bv[e], gv[e], to_f(rq[d][e]));
+                acc2[o][4 * q + e] = v;
+                s1 += v;
+                s2 = fmaf(v, v, s2);
+              }
+            }
+          }
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        const float mean = s1 * (1.0f / C);
+        const float rstd = __builtin_amdgcn_rsqf(fmaxf(fmaf(-mean, mean, s2 * (1.0f / C)), 0.0f) + a.lnp_eps);
+        const float nmr = -mean * rstd;
+        int sg = 0;
+#pragma unroll
+        for (int t = 1; t < 4; ++t) sg += (t < a.lnp_nseg && (int)mc >= a.lnp_tok0[t]) ? 1 : 0;
+        const int local = (int)mc - a.lnp_tok0[sg];
+        const int hw = a.lnp_hw[sg], wd = a.lnp_wd[sg];
+        const int img = local / hw, rem = local - img * hw;
+        const int py = rem / wd, px = rem - py * wd;
+        const int64_t prow = (int64_t)a.lnp_out0[sg] + ((int64_t)img * (hw / wd / 2) + (py >> 1)) * (wd >> 1) + (px >> 1);
+        T* const dst = Op + prow * (4 * C) + ((py & 1) * 2 + (px & 1)) * C;
+        const float* sLw = reinterpret_cast<const float*>(smem + CF::kLn);
+        asm volatile("" : "+v"(sLw));
+#pragma unroll
+        for (int o = 0; o < NO; ++o)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            uint2 pk[2];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+              const int q = 2 * pr + d;
+              const int n = 32 * o + 8 * q + 4 * lh;
+              const f32x4 wv = *(const f32x4*)(sLw + n);
+              const f32x4 cv = *(const f32x4*)(sLw + C + n);
+              t4 o4;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o4[e] = from_f<T>(fmaf(fmaf(acc2[o][4 * q + e], rstd, nmr), wv[e], cv[e]));
+              pk[d] = __builtin_bit_cast(uint2, o4);
+            }
+            const auto sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+            const u32x4 w = {sx[0], sy[0], sx[1], sy[1]};
+            if (m < a.M) *(u32x4*)(dst + 32 * o + 16 * pr + 8 * lh) = w;
+          }
+      } else
 #pragma unroll
       for (int o = 0; o < NO; ++o)
 #pragma unroll

@@ -17,6 +17,13 @@ template <typename T, int C> static int launch_xs_mlp_c(const XsMlpArgs& a, hipS
   GCV_ENSURE_LDS((xs_mlp_kernel<T, C>), SMEM);
   const int npass = cdiv(a.M, 256);
   const int nwg = npass < 256 ? npass : 256;               // one persistent workgroup per CU
+  if (a.lnp_nseg > 0) {                                    // last block of the stage: LayerNorm2d + space-to-depth epilogue
+    GCV_REQUIRE(a.lnp_w && a.lnp_b && a.lnp_nseg <= 4, "xs MLP: LN-patchify epilogue arguments");
+    GCV_ENSURE_LDS((xs_mlp_kernel<T, C, true>), SMEM);
+    hipLaunchKernelGGL((xs_mlp_kernel<T, C, true>), dim3(nwg), dim3(512), SMEM, s, a, npass);
+    GCV_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL((xs_mlp_kernel<T, C>), dim3(nwg), dim3(512), SMEM, s, a, npass);
   GCV_CHECK_HIP(hipGetLastError());
   return 0;
