@@ -40,7 +40,8 @@ SWIN_HEADS = (3, 6, 12, 24)
 # weight the HIP path keeps in the storage dtype (the GEMM / conv-as-GEMM weights; biases, LayerNorm affine, layer
 # scale, depthwise taps (except those of the 56-pixel C = 96 maps, which are an MFMA operand: csrc/dwconv_mfma.h), the
 # first 3->16 convs, the last 16->3 transposed convs and the 500->2 layer stay fp32, as in genconvit_amd/csrc/net_impl.h) and (c) every activation at the points where the HIP path stores it in HBM or
-# feeds it to a 16-bit MFMA operand — all arithmetic stays fp32, like the kernels' accumulators.  With no storage
+# feeds it to a 16-bit MFMA operand (not: the output of the last block of stages 0 / 1, whose LayerNorm2d runs in that block's
+# epilogue) — all arithmetic stays fp32, like the kernels' accumulators.  With no storage
 # dtype set (the default) ``_q`` returns its argument untouched: the fp32 oracle is bit-for-bit what it was.
 _STORE = None
 
@@ -97,9 +98,10 @@ def _ln2d(x, w, b, eps):
     return F.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), w, b, eps).permute(0, 3, 1, 2)
 
 
-def convnext_block(sd, p, x):
+def convnext_block(sd, p, x, store=True):
     """timm 0.6.5 ConvNeXtBlock.forward: dw7x7 -> LN(NHWC)
-    -> fc1 -> exact GELU -> fc2 -> * gamma -> + shortcut."""
+    -> fc1 -> exact GELU -> fc2 -> * gamma -> + shortcut.  ``store=False``: the block's output is not a storage point
+    (the HIP path applies the next stage's LayerNorm2d in this block's epilogue, on the fp32 values)."""
     c = x.shape[1]
     w_dw = sd[p + "conv_dw.weight"]
     if c == 96 and x.shape[-1] == 56:       # the HIP path runs these taps on the matrix pipe for 16-bit storage
@@ -112,7 +114,7 @@ def convnext_block(sd, p, x):
     y = F.linear(y, _q(sd[p + "mlp.fc2.weight"]), sd[p + "mlp.fc2.bias"])
     y = y.permute(0, 3, 1, 2)
     y = y * sd[p + "gamma"].reshape(1, -1, 1, 1)
-    return _q(y + x)
+    return _q(y + x) if store else y + x
 
 
 def convnext_tiny(sd, prefix, x, taps=None, store_out=True):
@@ -131,7 +133,11 @@ def convnext_tiny(sd, prefix, x, taps=None, store_out=True):
             x = _q(F.conv2d(x, _q(sd[p + f"stages.{i}.downsample.1.weight"]),
                             sd[p + f"stages.{i}.downsample.1.bias"], stride=2))
         for j in range(depth):
-            x = convnext_block(sd, p + f"stages.{i}.blocks.{j}.", x)
+            # the last block of stages 0 and 1 hands its fp32 output to the stage boundary's LayerNorm (epilogue fusion in
+            # csrc/fused_mlp_res.h — only for launches of 65536 tokens and more — and csrc/xs_mlp.h)
+            tokens = x.shape[0] * x.shape[2] * x.shape[3]
+            fused = j == depth - 1 and (i == 1 or (i == 0 and tokens >= 65536)) and x.shape[2] % 2 == 0
+            x = convnext_block(sd, p + f"stages.{i}.blocks.{j}.", x, store=not fused)
         if taps is not None:
             taps[f"stage{i}"] = x
     x = x.mean((2, 3), keepdim=True)
