@@ -295,6 +295,24 @@ def test_full_size_config3_vae_batch32_bf16(sd_vae):
     assert err <= 5e-2 and err_same <= 5e-2
 
 
+@pytest.mark.parametrize("B", [33, 67])
+def test_odd_batches_16bit_against_the_fp32_path(B):
+    """Odd image counts in 16-bit storage: the 112-pixel segment of the VAE's merged pass then holds 784 B tokens, which is not
+    a multiple of the 32-token wave tiles, so tiles straddle the segment boundary in the MLP kernels whose epilogue applies the
+    stage boundary's LayerNorm + space-to-depth per segment (fused_mlp_res.h, xs_mlp.h); B = 67 also runs the matrix-pipe
+    dw kernel with ragged 19-row bands.  Checked against the fp32 path of the same library (itself within 2e-6 of the oracle
+    at B = 32), frame by frame."""
+    x = synth.make_frames(B, name="odd")
+    eps = synth.make_eps(B, name="odd").cuda()
+    ref = GenConViT.from_modules(ed_model(), vae_model(), net="genconvit")(x.cuda(), eps=eps).float().cpu()
+    for dtype, bound in ((torch.float16, 4e-3), (torch.bfloat16, 5e-2)):
+        g = GenConViT.from_modules(ed_model(dtype), vae_model(dtype), net="genconvit")
+        got = g(x.cuda(), eps=eps).float().cpu()
+        err = (got - ref).abs().max().item()
+        print(f"\ngenconvit {dtype} B={B}: all rows vs the fp32 path: {err:.2e}")
+        assert got.shape == (2 * B, 2) and torch.isfinite(got).all() and err <= bound
+
+
 # ----------------------------------------------------------------------------- Swin-T embedder (row A6)
 def test_full_size_config4_genconvit_batch128_fp16(golden):
     """BASELINE.json configs[3]: genconvit, batch 128, fp16 — the batch size at which the large-M kernels run
