@@ -88,6 +88,9 @@ SIGNATURES = {
     "gcv_k_mean_tokens": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gcv_k_fused_mlp": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_int, c_void_p]),
+    "gcv_k_fused_mlp_lnp": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_int, c_void_p]),
     "gcv_k_fused_mlp_timed": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }

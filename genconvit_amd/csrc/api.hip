@@ -124,10 +124,25 @@ static int to_map(const gcv_tensor_desc* w, int n, TensorMap& m) {
 // C = 96 / 192: the fused kernels; C = 384: the pw1 / pw2 kernel pair with its fragment-major hidden tensor.
 // iters == 0: one launch.  iters > 0 (gcv_k_fused_mlp_timed): the weights are packed once, then `iters` launches are timed
 // with HIP events on the stream; ms[0] = average of the whole MLP, ms[1] / ms[2] = pw1 / pw2 of the C = 384 pair (else 0).
+// lnp != nullptr (gcv_k_fused_mlp_lnp): the stage boundary's LayerNorm2d + 2x2 space-to-depth in the epilogue (C = 96 at
+// M >= 65536 tokens, C = 192), `out` is then the patchified (M/4, 4C) tensor.
+struct LnpSpec {
+  const float *w, *b;
+  float eps;
+  int nseg;
+  const int *tok0, *hw, *wd, *out0;
+};
+template <typename A> static void set_lnp(A& a, const LnpSpec* l) {
+  if (!l) return;
+  a.lnp_w = l->w; a.lnp_b = l->b; a.lnp_eps = l->eps; a.lnp_nseg = l->nseg;
+  for (int i = 0; i < l->nseg && i < 4; ++i) {
+    a.lnp_tok0[i] = l->tok0[i]; a.lnp_hw[i] = l->hw[i]; a.lnp_wd[i] = l->wd[i]; a.lnp_out0[i] = l->out0[i];
+  }
+}
 template <typename T>
 static int k_mlp_dispatch(int C, const void* x, const void* w1, const float* b1, const float* w2_f32, const float* b2,
                           const float* gamma, const void* resid, void* out, int M, hipStream_t s, int iters = 0,
-                          float* ms = nullptr) {
+                          float* ms = nullptr, const LnpSpec* lnp = nullptr) {
   struct DevBuf {                                  // freed on every exit path (after the stream has drained)
     void* p = nullptr;
     hipStream_t s;
@@ -157,6 +172,21 @@ static int k_mlp_dispatch(int C, const void* x, const void* w1, const float* b1,
     return 0;
   };
   if (ms) ms[0] = ms[1] = ms[2] = 0.0f;
+  if (lnp) {
+    GCV_REQUIRE(lnp->nseg >= 1 && lnp->nseg <= 4 && lnp->w && lnp->b && lnp->tok0 && lnp->hw && lnp->wd && lnp->out0,
+                "fused MLP with LN-patchify epilogue: 1..4 segments and their tables");
+    GCV_REQUIRE((C == 96 && fused_mlp_res_applies(C, M)) || xs_mlp_default(C),
+                "the LN-patchify epilogue exists at C = 96 (M >= 65536 tokens) and C = 192");
+    int64_t covered = 0;
+    for (int i = 0; i < lnp->nseg; ++i) {
+      const int end = i + 1 < lnp->nseg ? lnp->tok0[i + 1] : M;
+      const int wd = lnp->wd[i], hw = lnp->hw[i];
+      GCV_REQUIRE(wd > 0 && hw > 0 && hw % wd == 0 && wd % 2 == 0 && (hw / wd) % 2 == 0 && lnp->tok0[i] == covered &&
+                      end > lnp->tok0[i] && (end - lnp->tok0[i]) % hw == 0 && lnp->out0[i] * 4 == lnp->tok0[i],
+                  "LN-patchify segments: contiguous whole images with even height and width");
+      covered = end;
+    }
+  }
   if (mlp_pair_supported(C)) {
     GCV_CHECK_HIP(hipMalloc(&w1f.p, (size_t)4 * C * C * 2));
     GCV_CHECK_HIP(hipMalloc(&hid.p, mlp_pair_hidden_bytes(M, C)));
@@ -174,9 +204,11 @@ static int k_mlp_dispatch(int C, const void* x, const void* w1, const float* b1,
     GCV_CHECK_HIP(hipMalloc(&w1f.p, xs_mlp_packed_elems(C) * sizeof(T)));
     GCV_TRY((launch_pack_xs_mlp<T, float>((const T*)w1, w2_f32, (T*)w1f.p, C, s)));
     XsMlpArgs xa{x, w1f.p, b1, b2, gamma, resid, out, M};
+    set_lnp(xa, lnp);
     return timed([&] { return launch_xs_mlp<T>(xa, C, s); }, ms);
   }
   MlpArgs a{x, w1, b1, w2c.p, b2, gamma, resid, out, M};
+  set_lnp(a, lnp);
   GCV_TRY(launch_pack_w2_chunks<T>(w2_f32, (T*)w2c.p, C, s));
   return timed([&] { return launch_fused_mlp<T>(a, C, s); }, ms);
 }
@@ -512,6 +544,17 @@ int gcv_k_fused_mlp(int dtype, int C, const void* x, const void* w1, const float
   GCV_REQUIRE(dtype == GCV_F16 || dtype == GCV_BF16, "the MLP kernels are built for 16-bit storage");
   if (dtype == GCV_F16) return k_mlp_dispatch<half_t>(C, x, w1, b1, w2_f32, b2, gamma, resid, out, M, (hipStream_t)s);
   return k_mlp_dispatch<bf16_t>(C, x, w1, b1, w2_f32, b2, gamma, resid, out, M, (hipStream_t)s);
+}
+
+int gcv_k_fused_mlp_lnp(int dtype, int C, const void* x, const void* w1, const float* b1, const float* w2_f32,
+                        const float* b2, const float* gamma, const void* resid, const float* ln_w, const float* ln_b,
+                        float eps, int nseg, const int* tok0, const int* hw, const int* wd, const int* out0, void* out, int M,
+                        gcv_stream s) {
+  GCV_REQUIRE(dtype == GCV_F16 || dtype == GCV_BF16, "the MLP kernels are built for 16-bit storage");
+  const LnpSpec l{ln_w, ln_b, eps, nseg, tok0, hw, wd, out0};
+  if (dtype == GCV_F16)
+    return k_mlp_dispatch<half_t>(C, x, w1, b1, w2_f32, b2, gamma, resid, out, M, (hipStream_t)s, 0, nullptr, &l);
+  return k_mlp_dispatch<bf16_t>(C, x, w1, b1, w2_f32, b2, gamma, resid, out, M, (hipStream_t)s, 0, nullptr, &l);
 }
 
 int gcv_k_fused_mlp_timed(int dtype, int C, const void* x, const void* w1, const float* b1, const float* w2_f32,

@@ -200,6 +200,16 @@ int gcv_k_mean_tokens(int dtype, const void* x, void* out, int nimg, int L, int 
  * (timm ConvNeXtBlock: mlp.fc1 -> GELU -> mlp.fc2 -> * gamma -> + shortcut).  w2_f32: (C,4C) fp32 device. */
 int gcv_k_fused_mlp(int dtype, int C, const void* x, const void* w1, const float* b1, const float* w2_f32,
                     const float* b2, const float* gamma, const void* resid, void* out, int M, gcv_stream s);
+/* The last block of ConvNeXt stage 0 / 1 as the network runs it: the MLP above with the stage boundary's
+ * `downsample` LayerNorm2d + the 2x2 space-to-depth of its Conv2d(k=2, s=2) in the epilogue (timm ConvNeXtStage.downsample,
+ * SURVEY A.1; call sites model/genconvit_ed.py:82-83, model/genconvit_vae.py:111-112).  Tokens [tok0[i], tok0[i+1]) (the
+ * last segment ends at M) are whole images of hw[i] = H*W pixels, W = wd[i], H and W even; `out` receives the patch rows
+ * (M/4, 4C), (dy, dx, c) innermost, segment i starting at row out0[i] = tok0[i] / 4; the (M, C) residual stream is not
+ * written.  C = 96 (M >= 65536 tokens: the LDS-resident kernel) or C = 192; nseg <= 4; host int arrays. */
+int gcv_k_fused_mlp_lnp(int dtype, int C, const void* x, const void* w1, const float* b1, const float* w2_f32,
+                        const float* b2, const float* gamma, const void* resid, const float* ln_w, const float* ln_b,
+                        float eps, int nseg, const int* tok0, const int* hw, const int* wd, const int* out0, void* out, int M,
+                        gcv_stream s);
 /* The same launch, timed: the weights are packed once, then `iters` launches of the MLP kernel(s) alone are bracketed by
  * HIP events on `s` (the call synchronises).  ms3[0] = average ms per MLP; for the C = 384 kernel pair ms3[1] / ms3[2] are
  * pw1+GELU / pw2+scale+residual timed separately, else 0.  Used by profiles/microbench.py; `out` may alias `resid`. */

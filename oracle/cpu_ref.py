@@ -38,10 +38,10 @@ SWIN_HEADS = (3, 6, 12, 24)
 # "for 16-bit report the delta vs the fp32 oracle and vs a same-dtype CPU restatement".  Inside
 # ``with storage_dtype(torch.float16 | torch.bfloat16):`` the functions below round (a) the input frames, (b) every
 # weight the HIP path keeps in the storage dtype (the GEMM / conv-as-GEMM weights; biases, LayerNorm affine, layer
-# scale, depthwise taps (except those of the 56-pixel C = 96 maps, which are an MFMA operand: csrc/dwconv_mfma.h), the
+# scale, depthwise taps (except those of the 56-pixel C = 96 maps in launches of 64 images and more, where they are an MFMA operand: csrc/dwconv_mfma.h, ``Launch`` below), the
 # first 3->16 convs, the last 16->3 transposed convs and the 500->2 layer stay fp32, as in genconvit_amd/csrc/net_impl.h) and (c) every activation at the points where the HIP path stores it in HBM or
-# feeds it to a 16-bit MFMA operand (not: the output of the last block of stages 0 / 1, whose LayerNorm2d runs in that block's
-# epilogue) — all arithmetic stays fp32, like the kernels' accumulators.  With no storage
+# feeds it to a 16-bit MFMA operand (not: the output of the last block of stage 1 and, in launches of 65536 tokens and more, of
+# stage 0, whose LayerNorm2d runs in that block's epilogue: ``Launch`` below) — all arithmetic stays fp32, like the kernels' accumulators.  With no storage
 # dtype set (the default) ``_q`` returns its argument untouched: the fp32 oracle is bit-for-bit what it was.
 _STORE = None
 
@@ -98,14 +98,34 @@ def _ln2d(x, w, b, eps):
     return F.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), w, b, eps).permute(0, 3, 1, 2)
 
 
-def convnext_block(sd, p, x, store=True):
+# Launch-geometry thresholds of the HIP path that decide WHERE it rounds in 16-bit storage.  They are the oracle's own copy
+# (this file shares no table with the product); tests/test_host_cpu.py parses the product headers and asserts they agree.
+FUSED_LNP_MIN_TOKENS = 65536     # csrc/fused_mlp.h fused_mlp_res_applies: C = 96 launches of at least this many tokens run the
+                                 # LDS-resident MLP, the only C = 96 kernel with the LayerNorm-patchify epilogue
+DW_MFMA_MIN_IMAGE_ROWS = 14 * 256   # csrc/dwconv_roll_impl.h long_bands: images x rows of a C = 96 / 56-pixel dw launch from
+                                    # which the taps run on the matrix pipe (as a 16-bit MFMA operand)
+
+
+class Launch:
+    """What one ConvNeXt pass of the HIP path looks like from the launch side (csrc/net_impl.h run_convnext): the passes of
+    one network that share weights are concatenated on the token axis, so the dispatch rules above see the totals, not the
+    single pass the functional restatement evaluates.  ``stage0_tokens``: tokens of ALL segments of the launch at stage 0;
+    ``dw_images``: images in the depthwise launch this pass's geometry belongs to (neighbouring segments of one geometry
+    share a launch)."""
+
+    def __init__(self, stage0_tokens, dw_images):
+        self.stage0_tokens, self.dw_images = int(stage0_tokens), int(dw_images)
+
+
+def convnext_block(sd, p, x, store=True, mfma_taps=False):
     """timm 0.6.5 ConvNeXtBlock.forward: dw7x7 -> LN(NHWC)
     -> fc1 -> exact GELU -> fc2 -> * gamma -> + shortcut.  ``store=False``: the block's output is not a storage point
-    (the HIP path applies the next stage's LayerNorm2d in this block's epilogue, on the fp32 values)."""
+    (the HIP path applies the next stage's LayerNorm2d in this block's epilogue, on the fp32 values).  ``mfma_taps``: the
+    HIP path runs this block's taps on the matrix pipe (csrc/dwconv_mfma.h), i.e. as an MFMA operand in the storage dtype."""
     c = x.shape[1]
     w_dw = sd[p + "conv_dw.weight"]
-    if c == 96 and x.shape[-1] == 56:       # the HIP path runs these taps on the matrix pipe for 16-bit storage
-        w_dw = _q(w_dw)                     # (csrc/dwconv_mfma.h): they are an MFMA operand in the storage dtype
+    if mfma_taps:
+        w_dw = _q(w_dw)
     y = F.conv2d(x, w_dw, sd[p + "conv_dw.bias"], padding=3, groups=c)
     y = y.permute(0, 2, 3, 1)
     y = _q(F.layer_norm(y, (c,), sd[p + "norm.weight"], sd[p + "norm.bias"], LN_EPS_CONVNEXT))
@@ -117,11 +137,14 @@ def convnext_block(sd, p, x, store=True):
     return _q(y + x) if store else y + x
 
 
-def convnext_tiny(sd, prefix, x, taps=None, store_out=True):
+def convnext_tiny(sd, prefix, x, taps=None, store_out=True, launch=None):
     """timm 0.6.5 ``convnext_tiny`` forward: stem -> 4 stages -> (norm_pre=Identity)
     -> head(global avg pool, LayerNorm2d, flatten, fc).  Called by the reference at
-    model/genconvit_ed.py:82-83 and model/genconvit_vae.py:111-112."""
+    model/genconvit_ed.py:82-83 and model/genconvit_vae.py:111-112.  ``launch`` (16-bit restatement only): the geometry of
+    the HIP launch this pass is a segment of; default = the pass on its own (gcv_convnext_forward)."""
     p = prefix
+    if launch is None:
+        launch = Launch(x.shape[0] * (x.shape[2] // 4) * (x.shape[3] // 4), x.shape[0])
     x = F.conv2d(x, sd[p + "stem.0.weight"], sd[p + "stem.0.bias"], stride=4)
     x = _q(_ln2d(x, sd[p + "stem.1.weight"], sd[p + "stem.1.bias"], LN_EPS_CONVNEXT))
     if taps is not None:
@@ -135,9 +158,10 @@ def convnext_tiny(sd, prefix, x, taps=None, store_out=True):
         for j in range(depth):
             # the last block of stages 0 and 1 hands its fp32 output to the stage boundary's LayerNorm (epilogue fusion in
             # csrc/fused_mlp_res.h — only for launches of 65536 tokens and more — and csrc/xs_mlp.h)
-            tokens = x.shape[0] * x.shape[2] * x.shape[3]
-            fused = j == depth - 1 and (i == 1 or (i == 0 and tokens >= 65536)) and x.shape[2] % 2 == 0
-            x = convnext_block(sd, p + f"stages.{i}.blocks.{j}.", x, store=not fused)
+            fused = (j == depth - 1 and (i == 1 or (i == 0 and launch.stage0_tokens >= FUSED_LNP_MIN_TOKENS))
+                     and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
+            mfma = i == 0 and x.shape[-1] == 56 and launch.dw_images * x.shape[2] >= DW_MFMA_MIN_IMAGE_ROWS
+            x = convnext_block(sd, p + f"stages.{i}.blocks.{j}.", x, store=not fused, mfma_taps=mfma)
         if taps is not None:
             taps[f"stage{i}"] = x
     x = x.mean((2, 3), keepdim=True)
@@ -154,8 +178,10 @@ def ed_forward(sd, images, taps=None):
     images = _q(images)
     encimg = ed_encoder(sd, images, taps)
     decimg = ed_decoder(sd, encimg, taps)
-    x1 = convnext_tiny(sd, "backbone.", decimg, store_out=False)
-    x2 = convnext_tiny(sd, "backbone.", images, taps, store_out=False)
+    # both passes are one 2B-image launch of one geometry (net_impl.h ed_forward)
+    la = Launch(2 * images.shape[0] * (images.shape[2] // 4) * (images.shape[3] // 4), 2 * images.shape[0])
+    x1 = convnext_tiny(sd, "backbone.", decimg, store_out=False, launch=la)
+    x2 = convnext_tiny(sd, "backbone.", images, taps, store_out=False, launch=la)
     x = torch.cat((x1, x2), dim=1)
     if taps is not None:
         taps["ed_feat"] = x
@@ -230,15 +256,19 @@ def resize224(x_hat):
     return F.interpolate(x_hat, size=(224, 224), mode="bilinear", align_corners=False, antialias=True)
 
 
-def vae_forward(sd, x, eps, as_written=False, want_kl=False, taps=None):
+def vae_forward(sd, x, eps, as_written=False, want_kl=False, taps=None, merged=False):
     """GenConViTVAE.forward, model/genconvit_vae.py:107-116.  cat order is
     [backbone(orig @224), backbone(x_hat @112)]; activation is ReLU (:104).
     Returns (logits, resized reconstruction, kl or None)."""
     x = _q(x)
     z, kl = vae_encoder(sd, x, eps, as_written, want_kl, taps)
     x_hat = vae_decoder(sd, z, taps)
-    x1 = convnext_tiny(sd, "convnext_backbone.", x, store_out=False)
-    x2 = convnext_tiny(sd, "convnext_backbone.", x_hat, store_out=False)
+    # 16-bit restatement: gcv_vae_forward on its own runs the two passes as two launches (backbone(x) on a side stream);
+    # inside gcv_genconvit_forward they are the two segments of one launch (``merged``: csrc/net_impl.h vae_forward)
+    B, t224, t112 = x.shape[0], (x.shape[2] // 4) * (x.shape[3] // 4), (x_hat.shape[2] // 4) * (x_hat.shape[3] // 4)
+    la1 = Launch(B * (t224 + t112), B) if merged else None
+    x1 = convnext_tiny(sd, "convnext_backbone.", x, store_out=False, launch=la1)
+    x2 = convnext_tiny(sd, "convnext_backbone.", x_hat, store_out=False, launch=la1)
     f = torch.cat((x1, x2), dim=1)
     if taps is not None:
         taps["vae_feat"] = f
@@ -263,7 +293,7 @@ def genconvit_forward(sd_ed, sd_vae, x, eps, net="genconvit", as_written=False):
     if net == "vae":
         return vae_forward(sd_vae, x, eps, as_written)[0]
     x1 = ed_forward(sd_ed, x)
-    x2 = vae_forward(sd_vae, x, eps, as_written)[0]
+    x2 = vae_forward(sd_vae, x, eps, as_written, merged=True)[0]
     return torch.cat((x1, x2), dim=0)
 
 

@@ -99,8 +99,10 @@ def install_import_shims():
             self.size, self.antialias = size, antialias
 
         def __call__(self, x):
-            return F.interpolate(x, size=self.size, mode="bilinear", align_corners=False,
-                                 antialias=self.antialias)
+            # (the CPU has no 16-bit antialiased kernel: the --fp16 runs below resize in fp32; the resized reconstruction is
+            #  the forward's second output and not on the logits path)
+            return F.interpolate(x.float(), size=self.size, mode="bilinear", align_corners=False,
+                                 antialias=self.antialias).to(x.dtype)
     tvt.Resize = Resize
     tv.transforms = tvt
     tm = types.ModuleType("timm")
@@ -200,6 +202,39 @@ def main():
     out["vae_recon_slice"] = slice64(r_recon)
     out["vae_feat_slice"] = slice64(taps["vae_feat"])
     out["vae_mse"] = cpu_ref.mse_per_frame(r_recon, x4).numpy()
+
+    # ---- the reference's own --fp16 pipeline (model/genconvit.py:24-25,38-39,59-61: model.half(), prediction.py feeds
+    # .half() frames): every module evaluates in torch.float16 on the CPU, the backbone stand-in included (its functional
+    # ops take the dtype of the half parameters, as timm's modules would after .half()).  torch.randn_like (:46) would draw a
+    # different, half-precision stream: it is pinned to the fp32 run's eps (rounded to half) so that the two runs differ by
+    # precision alone.  These vectors are the yardstick for the HIP path's fp16 storage.
+    m_ed.half()
+    r_ed_half = m_ed(x4.half())
+    assert r_ed_half.dtype == torch.float16
+    out["ed_logits_half"] = r_ed_half.float().numpy()
+    m_vae.half()
+    _randn_like = torch.randn_like
+    torch.randn_like = lambda t, **kw: eps.to(t.dtype)
+    try:
+        r_vae_half, _ = m_vae(x4.half())
+    finally:
+        torch.randn_like = _randn_like
+    assert r_vae_half.dtype == torch.float16
+    out["vae_logits_half"] = r_vae_half.float().numpy()
+    print("reference .half() vs reference fp32: ED %.3e  VAE %.3e" % (
+        (r_ed_half.float() - r_ed_logits).abs().max().item(), (r_vae_half.float() - r_vae_logits).abs().max().item()))
+    m_ed.bfloat16()
+    m_vae.bfloat16()
+    torch.randn_like = lambda t, **kw: eps.to(t.dtype)
+    try:
+        r_ed_bf = m_ed(x4.bfloat16())
+        r_vae_bf, _ = m_vae(x4.bfloat16())
+    finally:
+        torch.randn_like = _randn_like
+    out["ed_logits_bf16"] = r_ed_bf.float().numpy()
+    out["vae_logits_bf16"] = r_vae_bf.float().numpy()
+    print("reference .bfloat16() vs reference fp32: ED %.3e  VAE %.3e" % (
+        (r_ed_bf.float() - r_ed_logits).abs().max().item(), (r_vae_bf.float() - r_vae_logits).abs().max().item()))
 
     # GenConViT.forward (model/genconvit.py:66-75) cannot be constructed without weight files on
     # disk (its ctor torch.load()s weight/*.pth); its forward is 3 lines, restated here verbatim.

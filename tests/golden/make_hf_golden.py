@@ -65,7 +65,7 @@ def main(out):
     eps = torch.from_numpy(gold["vae_eps"])
     orig = cpu_ref.convnext_tiny
     try:
-        cpu_ref.convnext_tiny = lambda sd, prefix, xx, taps=None, store_out=True: \
+        cpu_ref.convnext_tiny = lambda sd, prefix, xx, taps=None, store_out=True, launch=None: \
             (hf_ed if prefix == "backbone." else hf_vae)(pixel_values=xx).logits
         res["ed_logits_hf"] = cpu_ref.ed_forward(sd_ed, x).numpy()
         res["vae_logits_hf"] = cpu_ref.vae_forward(sd_vae, x, eps)[0].numpy()

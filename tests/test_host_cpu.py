@@ -56,6 +56,28 @@ def test_product_never_imports_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
 
 
+def test_oracle_dispatch_thresholds_equal_the_product_headers():
+    """The same-dtype restatement rounds where the HIP path rounds, and two of those places depend on launch geometry:
+    the C = 96 LayerNorm-patchify epilogue (fused_mlp_res_applies) and the matrix-pipe depthwise taps (long_bands).  The
+    oracle keeps its own constants; this asserts they are what the product headers compute."""
+    from oracle import cpu_ref
+    csrc = os.path.join(REPO, "genconvit_amd", "csrc")
+    src = open(os.path.join(csrc, "fused_mlp.h")).read()
+    m = re.search(r"fused_mlp_res_applies\(int C, int64_t M\)\s*\{\s*return C == 96 && M >= ([0-9 *]+);", src)
+    assert m, "fused_mlp_res_applies changed shape: update the oracle's Launch rules with it"
+    assert eval(m.group(1)) == cpu_ref.FUSED_LNP_MIN_TOKENS
+    src = open(os.path.join(csrc, "dwconv_roll_impl.h")).read()
+    m = re.search(r"const bool long_bands = \(int64_t\)nimg \* H >= ([0-9 *]+);", src)
+    assert m, "the long_bands rule changed shape"
+    assert eval(m.group(1)) == cpu_ref.DW_MFMA_MIN_IMAGE_ROWS
+    assert re.search(r"GCV_DWM\(96, 8\);\s*#ifdef GCV_DWM_ALL", src), "matrix-pipe dw kernel: only C = 96 / 56 px is dispatched"
+    # and the rules as the restatement applies them: ED's two passes are one launch (B = 11 -> 68 992 tokens: fused, B = 10
+    # -> 62 720: not), the matrix-pipe taps need 64 images of 56 rows in one dw launch
+    la = cpu_ref.Launch(2 * 11 * 3136, 22)
+    assert la.stage0_tokens >= cpu_ref.FUSED_LNP_MIN_TOKENS > 2 * 10 * 3136
+    assert 63 * 56 < cpu_ref.DW_MFMA_MIN_IMAGE_ROWS <= 64 * 56
+
+
 # ----------------------------------------------------------------------------- host mirror API
 def test_config_keys():
     from genconvit_amd.model.config import load_config

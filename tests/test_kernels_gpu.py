@@ -1,6 +1,7 @@
 """Per-kernel parity on the MI355X: every HIP kernel (called through the C ABI's gcv_k_* entry
 points) against a plain PyTorch fp32 CPU reference of the same op.  fp32 storage must agree to
 ~1e-5; 16-bit storage is checked against the same fp32 math on inputs rounded to that dtype."""
+import ctypes
 import math
 
 import pytest
@@ -425,6 +426,58 @@ def test_fused_mlp_layerscale_residual(dt, C, M):
     kutil.call("gcv_k_fused_mlp", _lib.dtype_code(dtype), C, ptr(D(x, dtype)), ptr(D(w1, dtype)), ptr(D(b1)),
                ptr(D(w2)), ptr(D(b2)), ptr(D(gamma)), ptr(out), ptr(out), M)
     assert_close(out, want, tol(dtype, 2.0), "fused mlp")
+
+
+# segments: (images, H, W) per segment, in token order
+_LNP_CASES = [
+    (96, [(22, 56, 56)]),                          # one segment, 68 992 tokens: 2 156 wave tiles, none ragged
+    (96, [(21, 56, 56), (7, 28, 28)]),             # 65 856 + 5 488 tokens: the boundary is a tile edge (2 058 * 32)
+    (96, [(21, 56, 56), (9, 28, 28), (3, 14, 14)]),   # three geometries, last tile ragged (73 500 tokens)
+    (96, [(5, 56, 56), (67, 28, 28)]),             # 15 680 + 52 528: odd image count behind a boundary at token 490 * 32
+    (96, [(3, 30, 30), (23, 56, 54)]),             # non-square maps, boundary at 2 700 = 84 * 32 + 12: a tile straddles it
+    (192, [(3, 28, 28)]),                          # 2 352 tokens: ragged last pass (9.2 passes of 256)
+    (192, [(5, 28, 28), (5, 14, 14)]),             # 3 920 + 980: boundary at 122 * 32 + 16, inside a wave tile
+    (192, [(1, 14, 14), (2, 28, 28), (3, 6, 10)]),   # boundary at 196 = 6 * 32 + 4, non-square tail segment, 1 944 tokens
+    (192, [(67, 28, 28), (67, 14, 14)]),           # 65 660 tokens: 257 passes on 256 persistent workgroups (second pass)
+]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("C,segs", _LNP_CASES)
+def test_fused_mlp_layernorm_patchify_epilogue(dt, C, segs):
+    """Last block of ConvNeXt stage 0 / 1 as the network runs it in 16-bit storage: MLP + layer scale + shortcut, then the
+    stage boundary's LayerNorm2d and the 2x2 space-to-depth of its stride-2 conv in the same kernel's epilogue (timm
+    ConvNeXtStage.downsample; fused_mlp_res_kernel<T, true> at C = 96, xs_mlp_kernel<T, 192, true>).  Checked element-wise
+    against plain torch: F.layer_norm of the fp32 MLP output, then the patch gather, per segment."""
+    dtype = DTYPES[dt]
+    M = sum(n * h * w for n, h, w in segs)
+    x = q(rnd((M, C), 1, 1.5), dtype)
+    w1 = q(rnd((4 * C, C), 2, 1 / math.sqrt(C)), dtype)
+    w2 = q(rnd((C, 4 * C), 3, 1 / math.sqrt(4 * C)), dtype)
+    b1, b2, gamma = rnd((4 * C,), 4, 0.1), rnd((C,), 5, 0.1), rnd((C,), 6, 0.5)
+    res = q(rnd((M, C), 7), dtype)
+    lw, lb = rnd((C,), 8, 0.5) + 1.0, rnd((C,), 9, 0.1)
+    h = q(F.gelu(x @ w1.t() + b1), dtype)
+    y = res + gamma * (h @ w2.t() + b2)            # the residual stream the kernel keeps in registers (fp32)
+    yn = F.layer_norm(y, (C,), lw, lb, 1e-6)
+    want, tok0, hw, wd, out0, t = [], [], [], [], [], 0
+    for n, H, W in segs:
+        tok0.append(t); hw.append(H * W); wd.append(W); out0.append(t // 4)
+        v = yn[t:t + n * H * W].reshape(n, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5)
+        want.append(v.reshape(n * (H // 2) * (W // 2), 4 * C))
+        t += n * H * W
+    want = torch.cat(want)
+    out = torch.full((M // 4 + 3, 4 * C), 7.0, dtype=dtype, device=dev())
+    arr = lambda v: (ctypes.c_int * 4)(*(v + [0] * (4 - len(v))))
+    a_tok0, a_hw, a_wd, a_out0 = arr(tok0), arr(hw), arr(wd), arr(out0)
+    resd = D(res, dtype)
+    kutil.call("gcv_k_fused_mlp_lnp", _lib.dtype_code(dtype), C, ptr(D(x, dtype)), ptr(D(w1, dtype)), ptr(D(b1)),
+               ptr(D(w2)), ptr(D(b2)), ptr(D(gamma)), ptr(resd), ptr(D(lw)), ptr(D(lb)), 1e-6, len(segs), a_tok0, a_hw, a_wd,
+               a_out0, ptr(out), M)
+    assert torch.equal(resd.cpu(), res.to(dtype)), "the residual stream must not be written"
+    assert (out[M // 4:].float() == 7.0).all(), "rows behind the last patch row were written"
+    # y ~ U(-1, 1) + small: LayerNorm output of magnitude ~3 (lw up to 1.5, |z| up to ~2.5) -> scale 4
+    assert_close(out[:M // 4], want, tol(dtype, 4.0), "fused mlp + LN-patchify")
 
 
 # ----------------------------------------------------------------------------- LDS-DMA pipelined GEMM

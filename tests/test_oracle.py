@@ -81,6 +81,15 @@ def test_vae_matches_reference_golden(golden, sd_vae):
     assert torch.equal(z_a, z_b)
 
 
+def test_reference_16bit_runs_are_recorded_beside_the_fp32_golden(golden):
+    """tests/golden/make_golden.py also runs the reference's own classes after .half() / .bfloat16() (its --fp16 path,
+    model/genconvit.py:24-25): the committed deltas are the yardstick of the 16-bit GPU tests."""
+    want = {("ed", "half"): 9.3e-4, ("vae", "half"): 6.8e-4, ("ed", "bf16"): 7.8e-3, ("vae", "bf16"): 5.6e-3}
+    for (net, d), v in want.items():
+        got = np.abs(golden[f"{net}_logits_{d}"] - golden[f"{net}_logits"]).max()
+        assert abs(got - v) <= 0.02 * v + 1e-5, (net, d, got)
+
+
 def test_vote_matches_reference_golden(golden):
     logits = torch.from_numpy(golden["genconvit_logits"])
     y, val = cpu_ref.vote(logits)
