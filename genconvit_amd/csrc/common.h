@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <string>
 
+#include "diag/diag.h"     // diagnostic switches: all off in the product build
+
 namespace gcv {
 
 // ---- storage dtypes -------------------------------------------------------

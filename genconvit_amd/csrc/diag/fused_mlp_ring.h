@@ -32,7 +32,7 @@
 //   * epilogue: the x registers are dead after the last GEMM1 of a tile and take the residual rows (48 independent
 //     8-byte loads); (acc2 + b2) * gamma + resid is stored as 8-byte pieces straight from the accumulator layout
 #pragma once
-#include "fused_mlp.h"
+#include "../fused_mlp.h"
 
 namespace gcv {
 

@@ -2,8 +2,4 @@
 #include "dwconv_roll_impl.h"
 namespace gcv { GCV_INSTANTIATE_DW_ROLL(half_t) }
 
-#if GCV_DW_STAMPS
-extern "C" __attribute__((visibility("default"))) int gcv_debug_read_dw_stamps(unsigned long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gcv::gcv_dw_stamps), sizeof(unsigned long long) * n);
-}
-#endif
+GCV_DW_STAMP_READER      // (diag/diag.h: nothing unless the build defines GCV_DW_STAMPS)

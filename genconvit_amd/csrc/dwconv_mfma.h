@@ -37,9 +37,6 @@
 
 namespace gcv {
 
-#ifndef GCV_DWM_ABLATE
-#define GCV_DWM_ABLATE 0   // diagnostics: 1 no MFMAs, 2 no LayerNorm (reads, math, stores), 4 no operand gathers
-#endif
 
 template <typename T, int C, int NS> struct DwMfmaLds {
   static constexpr int W = 7 * NS;

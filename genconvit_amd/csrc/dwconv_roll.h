@@ -61,28 +61,6 @@ template <int L> __device__ __forceinline__ float dw_group_sum(float v) {
   else return wave_sum(v);
 }
 
-#ifndef GCV_DWR_ABLATE
-#define GCV_DWR_ABLATE 0   // diagnostics: 1 no tap FMAs, 2 no LN reduction, 4 no normalise/stores, 8 no input loads, 16 no barrier, 32 no priority rotation
-#endif
-#ifndef GCV_DW_STAMPS
-#define GCV_DW_STAMPS 0
-#endif
-#if GCV_DW_STAMPS
-// diagnostics (profiles/dw_stamps.py): s_memtime stamps of tap wave 0 (slots 0..7) and staging wave 0 (slots 8..15) of
-// workgroups 0..63 in the step GCV_DW_STAMP_IT; written to a buffer nothing else reads
-__device__ unsigned long long gcv_dw_stamps[64 * 32];
-#define GCV_DW_STAMP_IT 30
-#define DW_STAMP(cond, slot)                                                                    \
-  do {                                                                                          \
-    if ((cond) && blockIdx.x < 64) {                                                            \
-      unsigned long long _t;                                                                    \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");               \
-      gcv_dw_stamps[blockIdx.x * 32 + (slot)] = _t;                                             \
-    }                                                                                           \
-  } while (0)
-#else
-#define DW_STAMP(cond, slot) do { } while (0)
-#endif
 #define GCV_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 // ---- inline-asm LDS reads of one staged (fp32) input row; the offsets are instruction immediates ----

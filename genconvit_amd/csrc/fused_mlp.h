@@ -18,29 +18,8 @@
 #pragma once
 #include "gemm.h"
 
-#ifndef GCV_MLP_ABLATE
-#define GCV_MLP_ABLATE 0   // diagnostic builds only: 1 = no GELU, 2 = no weight streaming after chunk 0, 4 = no GEMM2
-#endif
-
-#ifndef GCV_MLP_STAMPS
-#define GCV_MLP_STAMPS 0   // diagnostic builds only: s_memtime stamps of workgroups 0..63 (wave 0) into a side buffer
-#endif
-
 namespace gcv {
 
-#if GCV_MLP_STAMPS
-__device__ unsigned long long gcv_mlp_stamps[64 * 16];
-#define GCV_STAMP(i)                                                                              \
-  do {                                                                                            \
-    if (blockIdx.x < 64 && threadIdx.x == 0) {                                                    \
-      unsigned long long _t;                                                                      \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");                   \
-      gcv_mlp_stamps[blockIdx.x * 16 + (i)] = _t;                                                 \
-    }                                                                                             \
-  } while (0)
-#else
-#define GCV_STAMP(i) do { } while (0)
-#endif
 
 struct MlpArgs {
   const void* X;       // (M, C) LayerNorm'ed dw-conv output

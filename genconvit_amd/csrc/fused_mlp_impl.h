@@ -5,7 +5,7 @@
 #include "fused_mlp.h"
 #include "fused_mlp_res.h"
 #ifdef GCV_EXPERIMENTS
-#include "fused_mlp_ring.h"      // opt-in LDS-DMA ring MLP (C = 192 / 384): measured slower, kept for A/B runs only
+#include "diag/fused_mlp_ring.h"      // opt-in LDS-DMA ring MLP (C = 192 / 384): measured slower, kept for A/B runs only
 #endif
 
 namespace gcv {

@@ -57,11 +57,6 @@ __global__ void __launch_bounds__(512, 1) fused_mlp_res_kernel(const MlpArgs a) 
   const int lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
 
-#if GCV_MLP_STAMPS
-#define RES_STAMP(slot) do { if (blockIdx.x < 64 && (threadIdx.x & 63) == 0) { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory"); if (threadIdx.x == 0) gcv_mlp_stamps[blockIdx.x * 16 + (slot)] = _t; if (threadIdx.x == 448) gcv_mlp_stamps[blockIdx.x * 16 + (slot) + 3] = _t; } } while (0)
-#else
-#define RES_STAMP(slot) do { } while (0)
-#endif
   RES_STAMP(10);
   // ---- weights -> LDS, once ----
   {

@@ -21,27 +21,8 @@
 
 namespace gcv {
 
-#ifndef GCV_GLDS_ABLATE
-#define GCV_GLDS_ABLATE 0     // diagnostics only: 1 = no MFMA/fragment reads, 2 = no steady-state loads, 4 = no epilogue math
-#endif
 #ifndef GCV_GLDS_STAGES
 #define GCV_GLDS_STAGES 2     // 64-byte-row ring: 2 x 20 KB leaves room for THREE workgroups per CU (-5 % at K = 384 vs 4 stages)
-#endif
-#ifndef GCV_GLDS_STAMPS
-#define GCV_GLDS_STAMPS 0     // diagnostics only: per-workgroup s_memtime stamps + HW_ID into a side buffer
-#endif
-#if GCV_GLDS_STAMPS
-__device__ unsigned long long gcv_glds_stamps[4096 * 8];
-#define GLDS_STAMP(i)                                                                 \
-  do {                                                                                \
-    if (blockIdx.x < 4096 && threadIdx.x == 0) {                                      \
-      unsigned long long _t;                                                          \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");       \
-      gcv_glds_stamps[blockIdx.x * 8 + (i)] = _t;                                     \
-    }                                                                                 \
-  } while (0)
-#else
-#define GLDS_STAMP(i) do { } while (0)
 #endif
 constexpr int kGldsBM = 128, kGldsBN = 192;
 // ring geometry by bytes per LDS row: 64 B (32 k) x 2 stages (40 KB: the epilogue staging then sets the footprint, 53 KB,
@@ -85,11 +66,7 @@ __global__ void __launch_bounds__(256, 2) gemm_glds_kernel(const GemmArgs g) {
   const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 96;
 
   GLDS_STAMP(0);
-#if GCV_GLDS_STAMPS
-  if (blockIdx.x < 4096 && threadIdx.x == 0)
-    gcv_glds_stamps[blockIdx.x * 8 + 5] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) |
-                                          ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
-#endif
+  GLDS_STAMP_HWID();
   const int ntn = g.N / BN;
   const int ntm = (g.M + BM - 1) / BM;
   const int bid = xcd_remap(blockIdx.x, ntm * ntn);

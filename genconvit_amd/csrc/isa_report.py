@@ -19,6 +19,14 @@ Checks (run by the Makefile on every build):
     tracked by SIInsertWaitcnts; correctness rests on no instruction touching the destination registers until the
     inline-asm s_waitcnt that retires them (lgkmcnt for ds_read, vmcnt for global_load).  A register-allocator copy,
     spill or any other use in between would read a value that has not landed: flagged as an error.
+
+ 3. the register cliff.  Several kernels sit at their register budget by design (dwconv_mfma.h: 42 tap operands + 56
+    accumulators + 12 gathered operands at the 128-register budget of a 16-wave workgroup; pw2f_kernel: 192 accumulators at
+    256): a compiler bump or an innocent edit can push one over, and what comes out is a kernel that is still correct and
+    several times slower (the two dw variants of DESIGN.md section 4.0 item 9 compiled to 220+ spilled registers).  Every
+    kernel's scratch (.private_segment_fixed_size) must stay within SCRATCH_BUDGET: 0 bytes unless listed, and the listed
+    ones are the few dwords hipcc 7.2 spills outside the steady-state loops today.  Raising an entry is a decision, not a
+    side effect.
 """
 import re
 import subprocess
@@ -26,21 +34,55 @@ import sys
 
 
 def demangle(n):
-    try:
-        return subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", n], capture_output=True, text=True).stdout.strip()
-    except Exception:
-        return n
+    for tool in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "c++filt"):
+        try:
+            out = subprocess.run([tool, n], capture_output=True, text=True).stdout.strip()
+            if out:
+                return out
+        except Exception:
+            pass
+    return n
+
+
+# bytes of scratch per lane a kernel may use: (regex on the MANGLED name — the image has no demangler that knows DF16_ —,
+# bytes); first match wins, default 0
+SCRATCH_BUDGET = [
+    (r"pw2f_kernelI\w+?Li384ELi384ELi3ELi8EE", 56),     # 13 dwords: the five DMA source pointers around the K loop's call sites
+    (r"xs_mlp_kernelI\w+?Li192ELb[01]EE", 20),          # 4 dwords in the pass prologue
+    (r"dwconv7_ln_roll_kernelI\w+?Li96ELi4EE", 8),      # 1 dword
+    (r"dwconv7_ln_kernelI\w+?Li768EE", 88),             # generic kernel of the 3x3 maps of the 112-pixel pass
+]
+
+
+def kernel_meta(path):
+    """[(mangled name, {vgpr, agpr, sgpr, spill, scratch, lds})] from the .amdgpu_metadata block of one .s file"""
+    out = []
+    s = open(path).read()
+    for b in re.split(r'^\s+- \.agpr_count:', s, flags=re.M)[1:]:
+        g = lambda k: int(re.search(r'\.%s:\s+(\S+)' % k, b).group(1))
+        out.append((re.search(r'\.name:\s+(\S+)', b).group(1),
+                    dict(agpr=int(b.split()[0]), vgpr=g('vgpr_count'), sgpr=g('sgpr_count'), spill=g('vgpr_spill_count'),
+                         scratch=g('private_segment_fixed_size'), lds=g('group_segment_fixed_size'))))
+    return out
 
 
 def report(paths):
     for path in paths:
-        s = open(path).read()
-        for b in re.split(r'^\s+- \.agpr_count', s, flags=re.M)[1:]:
-            g = lambda k: re.search(r'\.%s:\s+(\S+)' % k, b).group(1)
-            nm = demangle(g('name'))
-            nm = re.sub(r'\(.*', '', nm)[:110]
-            print(f"{nm:110s} vgpr {g('vgpr_count'):>4} sgpr {g('sgpr_count'):>4} spill {g('vgpr_spill_count')} "
-                  f"scratch {g('private_segment_fixed_size')} lds {g('group_segment_fixed_size')}")
+        for name, m in kernel_meta(path):
+            nm = re.sub(r'\(.*', '', demangle(name))[:110]
+            print(f"{nm:110s} vgpr {m['vgpr']:>4} agpr {m['agpr']:>4} sgpr {m['sgpr']:>4} spill {m['spill']:>3} "
+                  f"scratch {m['scratch']:>4} lds {m['lds']}")
+
+
+def check_scratch(path):
+    findings = []
+    for name, m in kernel_meta(path):
+        nm = re.sub(r'\(.*', '', demangle(name))
+        budget = next((b for pat, b in SCRATCH_BUDGET if re.search(pat, name)), 0)
+        if m['scratch'] > budget:
+            findings.append(f"{path}: {nm[:100]}: {m['scratch']} bytes of scratch per lane ({m['spill']} spilled VGPRs), budget "
+                            f"{budget} — register cliff (isa_report.py check 3)")
+    return findings
 
 
 REG = re.compile(r'\b([va])(\d+)\b|\b([va])\[(\d+):(\d+)\]')
@@ -159,6 +201,7 @@ if __name__ == "__main__":
         bad = []
         for p in args[1:]:
             bad += check_file(p)
+            bad += check_scratch(p)
         for b in bad:
             print(b)
         print(f"isa_report.py --check: {len(args) - 1} file(s), {len(bad)} finding(s)")

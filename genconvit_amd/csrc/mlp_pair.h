@@ -79,56 +79,6 @@ template <int C, int NW, int D> struct XsPw1Smem {
 
 #define GCV_XS_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory")
 
-#ifndef GCV_XS_ABLATE
-#define GCV_XS_ABLATE 0    // diagnostic builds only: 1 = no GELU arithmetic, 2 = no DMA after the prologue, 4 = no stores,
-#endif                     //                         8 = no MFMA, 16 = no fragment reads after the first
-#ifndef GCV_XS_PAIR
-#define GCV_XS_PAIR 1     // two hidden chunks per barrier (0: one, the first version of the kernel)
-#endif
-#ifndef GCV_XS_SGB
-#define GCV_XS_SGB 1      // 1 = 1 MFMA : 1 LDS read : n vector instructions (product); 0 / 2 / 3 diagnostics, see sub_block
-#endif
-#ifndef GCV_XS_STAMPS
-#define GCV_XS_STAMPS 0    // diagnostic builds only: s_memtime stamps of workgroups 0..63 (wave 0) into a side buffer
-#endif
-#ifndef GCV_XS_STAMP_WAVE
-#define GCV_XS_STAMP_WAVE 0
-#endif
-#if GCV_XS_STAMPS
-__device__ unsigned long long gcv_xs_stamps[64 * 64];
-#define XS_STAMP(i)                                                                   \
-  do {                                                                                \
-    if (blockIdx.x < 64 && blockIdx.y == 0 && threadIdx.x == 64 * GCV_XS_STAMP_WAVE) {  \
-      unsigned long long _t;                                                          \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");       \
-      gcv_xs_stamps[blockIdx.x * 64 + (i)] = _t;                                      \
-    }                                                                                 \
-  } while (0)
-#else
-#define XS_STAMP(i) do { } while (0)
-#endif
-#ifndef GCV_P2_ABLATE
-#define GCV_P2_ABLATE 0    // diagnostic builds only: 1 = no MFMA, 2 = no DMA in the K loop, 4 = fragment reads of chunk 0 only,
-#endif                     //                         8 = no epilogue loads / stores
-#ifndef GCV_P2_STAMPS
-#define GCV_P2_STAMPS 0    // diagnostic builds only: stamps of pw2f workgroups 0..63; P2_STAMP_WAVE picks the reporting wave
-#endif
-#ifndef GCV_P2_STAMP_WAVE
-#define GCV_P2_STAMP_WAVE 0
-#endif
-#if GCV_P2_STAMPS
-__device__ unsigned long long gcv_p2_stamps[64 * 64];
-#define P2_STAMP(i)                                                                   \
-  do {                                                                                \
-    if (blockIdx.x < 64 && threadIdx.x == 64 * GCV_P2_STAMP_WAVE) {                    \
-      unsigned long long _t;                                                          \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");       \
-      gcv_p2_stamps[blockIdx.x * 64 + (i)] = _t;                                      \
-    }                                                                                 \
-  } while (0)
-#else
-#define P2_STAMP(i) do { } while (0)
-#endif
 
 // grid = (ceil(M / (32 NW)), nsplit): workgroup (bx, by) owns tokens [32 NW bx, +32 NW) and hidden chunks
 // [by * nch_split, +nch_split) of the 4C/32

@@ -9,14 +9,5 @@ template int launch_pack_w2_frag<half_t, half_t>(const half_t*, half_t*, int, hi
 template int launch_pack_w2_frag<half_t, float>(const float*, half_t*, int, hipStream_t);
 }
 
-#if GCV_XS_STAMPS
-extern "C" __attribute__((visibility("default"))) int gcv_debug_read_xs_stamps(unsigned long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gcv::gcv_xs_stamps), sizeof(unsigned long long) * n);
-}
-#endif
-
-#if GCV_P2_STAMPS
-extern "C" __attribute__((visibility("default"))) int gcv_debug_read_p2_stamps(unsigned long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gcv::gcv_p2_stamps), sizeof(unsigned long long) * n);
-}
-#endif
+GCV_XS_STAMP_READER      // (diag/diag.h: nothing unless the build defines GCV_XS_STAMPS / GCV_P2_STAMPS)
+GCV_P2_STAMP_READER

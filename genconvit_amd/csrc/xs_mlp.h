@@ -88,25 +88,6 @@ template <int C> struct XsMlpCfg {
   static constexpr int NSB = NM / 4;                                    // sub-blocks of four MFMAs per step: 3 / 6
 };
 
-#ifndef GCV_XM_ABLATE
-#define GCV_XM_ABLATE 0    // diagnostic builds only: 1 = no GELU arithmetic, 2 = no DMA after the prologue, 8 = no MFMA
-#endif
-#ifndef GCV_XM_STAMPS
-#define GCV_XM_STAMPS 0
-#endif
-#if GCV_XM_STAMPS
-__device__ unsigned long long gcv_xm_stamps[64 * 64];
-#define XM_STAMP(i)                                                                   \
-  do {                                                                                \
-    if (blockIdx.x < 64 && threadIdx.x == 0) {                                        \
-      unsigned long long _t;                                                          \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");       \
-      gcv_xm_stamps[blockIdx.x * 64 + (i)] = _t;                                      \
-    }                                                                                 \
-  } while (0)
-#else
-#define XM_STAMP(i) do { } while (0)
-#endif
 
 #define GCV_XM_WAIT(N) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory")
 

@@ -6,8 +6,4 @@ template int launch_pack_xs_mlp<half_t, half_t>(const half_t*, const half_t*, ha
 template int launch_pack_xs_mlp<half_t, float>(const half_t*, const float*, half_t*, int, hipStream_t);
 }
 
-#if GCV_XM_STAMPS
-extern "C" __attribute__((visibility("default"))) int gcv_debug_read_xm_stamps(unsigned long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gcv::gcv_xm_stamps), sizeof(unsigned long long) * n);
-}
-#endif
+GCV_XM_STAMP_READER      // (diag/diag.h: nothing unless the build defines GCV_XM_STAMPS)
