@@ -191,7 +191,7 @@ static int k_mlp_dispatch(int C, const void* x, const void* w1, const float* b1,
     GCV_CHECK_HIP(hipMalloc(&w1f.p, (size_t)4 * C * C * 2));
     GCV_CHECK_HIP(hipMalloc(&hid.p, mlp_pair_hidden_bytes(M, C)));
     GCV_TRY((launch_pack_w1_frag<T, T>((const T*)w1, (T*)w1f.p, C, s)));
-    GCV_TRY((launch_pack_w2_frag<T, float>(w2_f32, (T*)w2c.p, C, s)));
+    GCV_TRY((launch_pack_w2_frag<T, float>(w2_f32, gamma, (T*)w2c.p, C, s)));
     MlpPairArgs a{x, w1f.p, b1, w2c.p, b2, gamma, resid, out, hid.p, M};
     if (iters > 0) {
       GCV_TRY(timed([&] { return launch_xs_pw1<T>(a, C, s); }, ms ? ms + 1 : nullptr));

@@ -59,6 +59,16 @@ int launch_dwconv7_ln(const T* x, const float* wdw, const float* bdw, const floa
   if (!generic && dwconv_roll_applicable<T>(H, W, C) &&
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) == 0)
     return launch_dwconv7_ln_roll<T>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, C, eps, s);
+  if (!generic && C == 768 && H == W && H <= 4) {          // stage-3 maps of small inputs (3 x 3 in the 112-pixel pass)
+#define GCV_DW_TINY(S)                                                                                              \
+    if (H == S) {                                                                                                   \
+      hipLaunchKernelGGL((dwconv7_ln_tiny_kernel<T, 768, S>), dim3(nimg), dim3(768), 0, s, x, wdw, bdw, lnw, lnb, y, eps); \
+      GCV_CHECK_HIP(hipGetLastError());                                                                             \
+      return 0;                                                                                                     \
+    }
+    GCV_DW_TINY(1) GCV_DW_TINY(2) GCV_DW_TINY(3) GCV_DW_TINY(4)
+#undef GCV_DW_TINY
+  }
   switch (C) {
     case 96:  return launch_dw_c<T, 96>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);
     case 192: return launch_dw_c<T, 192>(x, wdw, bdw, lnw, lnb, y, nimg, H, W, eps, s);

@@ -34,7 +34,7 @@ struct MlpPairArgs {
   const void* X;        // (M, C) LayerNorm'ed dw-conv output, token-major
   const void* W1f;      // packed W1: [4C/32][C/16][2][32][8]
   const float* b1;      // (4C)
-  const void* W2f;      // packed W2: [4C/32][C/32][4][32][8]
+  const void* W2f;      // packed gamma * W2: [4C/32][C/32][4][32][8] (pack_w2_frag_kernel folds the layer scale in)
   const float* b2;      // (C)
   const float* gamma;   // (C)
   const void* resid;    // (M, C) block input (may alias out)
@@ -57,9 +57,12 @@ __global__ void __launch_bounds__(256) pack_w1_frag_kernel(const S* __restrict__
   const int p = (int)(t % KP), g = (int)(t / KP);
   out[i] = from_f<T>((float)w1[(int64_t)(32 * g + r) * C + 16 * p + 8 * kh + e]);
 }
-// W2 (C, 4C) row-major T -> [kc = k/32][nb = n/32][kq = (k%32)/8][r = n%32][e = k%8]
+// W2 (C, 4C) row-major -> [kc = k/32][nb = n/32][kq = (k%32)/8][r = n%32][e = k%8], with the block's layer scale folded
+// in: the packed weight is T(gamma[n] * W2[n][k]) (rounded once, from the source precision), so that pw2 accumulates
+// gamma * (W2 . h) directly and its accumulator can start at gamma * b2 and take the residual at any time
 template <typename T, typename S>
-__global__ void __launch_bounds__(256) pack_w2_frag_kernel(const S* __restrict__ w2, T* __restrict__ out, int C) {
+__global__ void __launch_bounds__(256) pack_w2_frag_kernel(const S* __restrict__ w2, const float* __restrict__ gamma,
+                                                           T* __restrict__ out, int C) {
   const int64_t total = (int64_t)4 * C * C;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
@@ -67,7 +70,7 @@ __global__ void __launch_bounds__(256) pack_w2_frag_kernel(const S* __restrict__
   const int64_t t = i >> 10;
   const int NB = C / 32;
   const int nb = (int)(t % NB), kc = (int)(t / NB);
-  out[i] = from_f<T>((float)w2[(int64_t)(32 * nb + r) * 4 * C + 32 * kc + 8 * kq + e]);
+  out[i] = from_f<T>(gamma[32 * nb + r] * (float)w2[(int64_t)(32 * nb + r) * 4 * C + 32 * kc + 8 * kq + e]);
 }
 
 // ---------------------------------------------------------------------------------------------- pw1: x-stationary
@@ -332,9 +335,21 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) xs_pw1_kernel(const MlpPairAr
 // ---------------------------------------------------------------------------------------------- pw2: fragment-major operands
 template <int C, int BN, int D, int TB = 8> struct Pw2fSmem {
   static constexpr int kStage = (TB + BN / 32) * 2048;     // TB token blocks + BN/32 channel blocks, one 32-deep K chunk
-  static constexpr int kBG = D * kStage;                   // b2 | gamma of the tile's BN channels
-  static constexpr int bytes = kBG + 2 * BN * 4;
+  static constexpr int kBG = D * kStage;                   // gamma * b2 of the tile's BN channels
+  // residual rows on their way into the accumulators (TRICKLE, below): two 1 KB slots per wave
+  static constexpr bool kTrickle = BN == C && D == 3 && TB == 8;
+  static constexpr int kRes = kBG + BN * 4;
+  static constexpr int bytes = kRes + (kTrickle ? 8 * 2048 : 0);
+  static_assert(bytes <= 160 * 1024, "LDS of a CU");
 };
+
+// f(integral_constant<int, I>) for I = B .. E-1, in order (a loop whose index is a constant expression in its body)
+template <int B, int E, typename F> __device__ __forceinline__ void pw2f_static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    pw2f_static_for<B + 1, E>(f);
+  }
+}
 
 // grid = ceil(M / (32 TB)) * (C / BN); 8 waves: BN = 384 -> 2 (M) x 4 (N), wave tile 128 tokens x 96 channels;
 //                                               BN = 192 -> 4 (M) x 2 (N), wave tile  64 tokens x 96 channels (TB = 8)
@@ -411,10 +426,11 @@ __global__ void __launch_bounds__(512, 2) pw2f_kernel(const MlpPairArgs a) {
     GCV_P2_PIECE(0); GCV_P2_PIECE(1); GCV_P2_PIECE(2); GCV_P2_PIECE(3); GCV_P2_PIECE(4);
     issue_advance();
   };
-  // b2 | gamma -> LDS (ordinary loads, before any DMA is in flight)
+  // gamma * b2 -> LDS (ordinary loads, before any DMA is in flight): W2f carries the layer scale, so the accumulator of
+  // out = resid + gamma * (W2 . h + b2) starts at gamma * b2 and the residual is simply added to it
   {
     float* sbg = reinterpret_cast<float*>(smem + SM::kBG);
-    for (int i = tid; i < 2 * BN; i += 512) sbg[i] = i < BN ? a.b2[nb0 * 32 + i] : a.gamma[nb0 * 32 + i - BN];
+    for (int i = tid; i < BN; i += 512) sbg[i] = a.b2[nb0 * 32 + i] * a.gamma[nb0 * 32 + i];
   }
   __syncthreads();
   P2_STAMP(40);
@@ -422,12 +438,54 @@ __global__ void __launch_bounds__(512, 2) pw2f_kernel(const MlpPairArgs a) {
   for (int s = 0; s < D - 1; ++s) issue();                 // K chunks 0 .. D-2 (NKC >= D - 1 by construction)
 
   f32x16 acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
+  {
+    const float* sbg = reinterpret_cast<const float*>(smem + SM::kBG) + wn * 96 + 4 * lh;
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bv = *(const f32x4*)(sbg + 32 * j + 8 * q);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = bv[e];
+      }
+  }
+
+  // ---- TRICKLE (full-width tiles): the residual rows do not wait for the epilogue.  Round 3 read them there, four
+  // dependent round trips to HBM per wave with nothing beside them: 20 of the kernel's 83 us, all 196 workgroups at once.
+  // Here piece r = (token block i, channel block j, half pr) of the wave's 128 x 96 residual tile — one 16-byte piece per
+  // lane, the layout the accumulator exchange below wants — is fetched by LDS-DMA into one of two private 1 KB slots at K
+  // step r (registers: none; it is issued BEFORE the step's ring pieces, so the counted wait of step r + 2, which retires
+  // the ring pieces of step r, retires it too) and added into acc[i][j] at step r + 2.  24 pieces, 48 steps.
+  constexpr bool TRK = SM::kTrickle;
+  constexpr int NPR = MI * NI * 2;
+  static_assert(!TRK || NPR + 2 < NKC - (D - 1), "the trickle ends inside the steady-state loop");
+  const T* const Rp = (const T*)a.resid;
+  unsigned char* const sres = smem + SM::kRes + wave * 2048;
+  const int ncol0 = nb0 * 32 + wn * 96;                    // first channel of this wave
+  auto row_of = [&](int i) { return (int64_t)(tb0 + wm * MI + i) * 32 + lr; };
+  auto issue_res = [&](int r) {
+    const int i = r / (2 * NI), j = (r >> 1) % NI, pr = r & 1;
+    const int64_t mm = row_of(i);
+    const int64_t mmc = mm < a.M ? mm : (int64_t)a.M - 1;
+    const T* src = Rp + mmc * C + ncol0 + 32 * j + 16 * pr + 8 * lh;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(sres + (r & 1) * 1024), 16, 0, 0);
+  };
+  auto take_res = [&](auto rc) {                           // acc[i][j][8 pr .. 8 pr + 7] += the landed piece
+    constexpr int r = decltype(rc)::value;
+    constexpr int i = r / (2 * NI), j = (r >> 1) % NI, pr = r & 1;
+    const u32x4 rw = *(const u32x4*)(sres + (r & 1) * 1024 + lane * 16);
+    const auto rx = __builtin_amdgcn_permlane32_swap(rw[0], rw[2], false, false);
+    const auto ry = __builtin_amdgcn_permlane32_swap(rw[1], rw[3], false, false);
+    const t4 rq[2] = {__builtin_bit_cast(t4, uint2{rx[0], ry[0]}), __builtin_bit_cast(t4, uint2{rx[1], ry[1]})};
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][4 * (2 * pr + d) + e] += to_f(rq[d][e]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the slot is refilled right behind this
+  };
 
   int slot_r = 0;
   // One K chunk = 2 k-steps x MI x NI MFMAs, issued in four fenced groups (k-step s = g / 2, token blocks of half g % 2).
@@ -481,12 +539,34 @@ __global__ void __launch_bounds__(512, 2) pw2f_kernel(const MlpPairArgs a) {
   // steady state: chunk kc has landed when at most (D-2) younger stages are outstanding; its slot's previous tenant
   // (chunk kc-1's neighbour in the ring) was left by every wave before this barrier, so the refill goes there
   constexpr int NSTEADY = NKC - (D - 1);
+  int kc0 = 0;
+  if constexpr (TRK) {
+    // steps 0 .. NPR + 1: one residual piece per step rides in front of the ring pieces, so a stage is PPW + 1 operations
+    // (at step NPR + 1 the two younger stages hold one residual piece between them: the larger count would let the ring
+    // pieces of step NPR + 1's chunk pass unretired, hence the loop ends at NPR and the tail uses the plain count, which
+    // is merely early for one step)
+    constexpr int WAITR = (D - 2) * (PPW + 1);
+    // (straight-line code: which accumulator block a step feeds must be a constant — a run-time switch over the 24 blocks
+    //  made hipcc spill 761 registers)
+    pw2f_static_for<0, NPR + 1>([&](auto kcc) {
+      constexpr int kc = decltype(kcc)::value;
+      if constexpr (kc == 0) GCV_XS_WAIT(WAITN);           // the younger stage is a prologue stage: no residual piece in it
+      else GCV_XS_WAIT(WAITR);
+      if constexpr (kc >= 2) take_res(std::integral_constant<int, kc - 2>{});
+      if constexpr (kc < NPR) issue_res(kc);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(std::true_type{});
+    });
+    kc0 = NPR + 1;
+  }
 #pragma unroll 1
-  for (int kc = 0; kc < NSTEADY; ++kc) {
+  for (int kc = kc0; kc < NSTEADY; ++kc) {
     if (kc >= 8 && kc < 16) P2_STAMP(4 * (kc - 8));
     GCV_XS_WAIT(WAITN);
     if (kc >= 8 && kc < 16) P2_STAMP(4 * (kc - 8) + 1);
-    if (kc >= 8 && kc < 16) P2_STAMP(4 * (kc - 8) + 2);
+    if constexpr (TRK) {
+      if (kc == NPR + 1) take_res(std::integral_constant<int, NPR - 1>{});
+    }
     compute(std::true_type{});
     if (kc >= 8 && kc < 16) P2_STAMP(4 * (kc - 8) + 3);
   }
@@ -497,15 +577,11 @@ __global__ void __launch_bounds__(512, 2) pw2f_kernel(const MlpPairArgs a) {
   }
 
   P2_STAMP(41);
-  // ---- epilogue: out = resid + gamma * (acc + b2), token-major rows.  A row's 16-byte piece (channels 16 pr + 8 lh ..
-  // + 7 of block j) is loaded / stored whole; v_permlane32_swap (its own inverse) converts between that and the
-  // accumulator's (8q + 4lh) halves.  Residual rows are fetched one token block ahead of their use.
-  const float* sB2_ = reinterpret_cast<const float*>(smem + SM::kBG);
-  const float* sG_ = sB2_ + BN;
-  const T* Rp = (const T*)a.resid;
+  // ---- epilogue, token-major rows.  A row's 16-byte piece (channels 16 pr + 8 lh .. + 7 of block j) is stored (and, without
+  // the trickle, loaded) whole; v_permlane32_swap (its own inverse) converts between that and the accumulator's (8q + 4lh)
+  // halves.  TRICKLE: the accumulator already is the result.  Otherwise out = resid + acc (acc started at gamma * b2 and W2f
+  // carries gamma), the residual rows fetched one token block ahead of their use.
   T* Op = (T*)a.out;
-  const int ncol0 = nb0 * 32 + wn * 96;                    // first channel of this wave
-  auto row_of = [&](int i) { return (int64_t)(tb0 + wm * MI + i) * 32 + lr; };
   auto load_res = [&](int i, u32x4 (&rr)[NI][2]) {
     const int64_t mm = row_of(i);
     const int64_t mmc = mm < a.M ? mm : (int64_t)a.M - 1;
@@ -516,29 +592,26 @@ __global__ void __launch_bounds__(512, 2) pw2f_kernel(const MlpPairArgs a) {
   };
   auto finish = [&](int i, const u32x4 (&rr)[NI][2]) {
     const int64_t mm = row_of(i);
-    // (pointers through an empty asm: keeps the b2 / gamma LDS reads, which do not depend on i, from being hoisted
-    //  out of the token-block loop and spilled)
-    const float* sB2 = sB2_;
-    const float* sG = sG_;
-    asm volatile("" : "+v"(sB2), "+v"(sG));
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
-        const u32x4 rw = rr[j][pr];
-        const auto rx = __builtin_amdgcn_permlane32_swap(rw[0], rw[2], false, false);
-        const auto ry = __builtin_amdgcn_permlane32_swap(rw[1], rw[3], false, false);
-        const t4 rq[2] = {__builtin_bit_cast(t4, uint2{rx[0], ry[0]}), __builtin_bit_cast(t4, uint2{rx[1], ry[1]})};
+        t4 rq[2];
+        if constexpr (!TRK) {
+          const u32x4 rw = rr[j][pr];
+          const auto rx = __builtin_amdgcn_permlane32_swap(rw[0], rw[2], false, false);
+          const auto ry = __builtin_amdgcn_permlane32_swap(rw[1], rw[3], false, false);
+          rq[0] = __builtin_bit_cast(t4, uint2{rx[0], ry[0]});
+          rq[1] = __builtin_bit_cast(t4, uint2{rx[1], ry[1]});
+        }
         uint2 pk[2];
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
           const int q = 2 * pr + d;
-          const int nl = wn * 96 + 32 * j + 8 * q + 4 * lh;
-          const f32x4 bv = *(const f32x4*)(sB2 + nl);
-          const f32x4 gv = *(const f32x4*)(sG + nl);
           t4 o4;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o4[e] = from_f<T>(fmaf(acc[i][j][4 * q + e] + bv[e], gv[e], to_f(rq[d][e])));
+          for (int e = 0; e < 4; ++e)
+            o4[e] = from_f<T>(TRK ? acc[i][j][4 * q + e] : acc[i][j][4 * q + e] + to_f(rq[d][e]));
           pk[d] = __builtin_bit_cast(uint2, o4);
         }
         const auto sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
@@ -548,13 +621,18 @@ __global__ void __launch_bounds__(512, 2) pw2f_kernel(const MlpPairArgs a) {
       }
   };
   u32x4 rA[NI][2], rB[NI][2];
-  load_res(0, rA);
+  if constexpr (TRK) {
 #pragma unroll
-  for (int i = 0; i < MI; i += 2) {
-    if (i + 1 < MI) load_res(i + 1, rB);
-    finish(i, rA);
-    if (i + 2 < MI) load_res(i + 2, rA);
-    if (i + 1 < MI) finish(i + 1, rB);
+    for (int i = 0; i < MI; ++i) finish(i, rA);
+  } else {
+    load_res(0, rA);
+#pragma unroll
+    for (int i = 0; i < MI; i += 2) {
+      if (i + 1 < MI) load_res(i + 1, rB);
+      finish(i, rA);
+      if (i + 2 < MI) load_res(i + 2, rA);
+      if (i + 1 < MI) finish(i + 1, rB);
+    }
   }
   P2_STAMP(42);
 }
@@ -565,7 +643,7 @@ template <typename T> int launch_pw2f(const MlpPairArgs& a, int C, hipStream_t s
 template <typename T> int launch_mlp_pair(const MlpPairArgs& a, int C, hipStream_t s);
 // (4C, C) / (C, 4C) row-major weights of type S (T or float) on the device -> fragment-major T
 template <typename T, typename S> int launch_pack_w1_frag(const S* w1, T* out, int C, hipStream_t s);
-template <typename T, typename S> int launch_pack_w2_frag(const S* w2, T* out, int C, hipStream_t s);
+template <typename T, typename S> int launch_pack_w2_frag(const S* w2, const float* gamma, T* out, int C, hipStream_t s);
 static inline bool mlp_pair_supported(int C) { return C == 384; }
 // bytes of the hidden workspace launch_mlp_pair needs for M tokens
 static inline size_t mlp_pair_hidden_bytes(int64_t M, int C) { return (size_t)((M + 31) / 32) * (size_t)(4 * C / 32) * 2048; }

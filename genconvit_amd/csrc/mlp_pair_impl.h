@@ -11,10 +11,10 @@ template <typename T, typename S> int launch_pack_w1_frag(const S* w1, T* out, i
   GCV_CHECK_HIP(hipGetLastError());
   return 0;
 }
-template <typename T, typename S> int launch_pack_w2_frag(const S* w2, T* out, int C, hipStream_t s) {
-  GCV_REQUIRE(C % 32 == 0, "pack_w2_frag: C must be a multiple of 32");
+template <typename T, typename S> int launch_pack_w2_frag(const S* w2, const float* gamma, T* out, int C, hipStream_t s) {
+  GCV_REQUIRE(C % 32 == 0 && gamma, "pack_w2_frag: C must be a multiple of 32, gamma is folded into the packed weight");
   const int64_t total = (int64_t)4 * C * C;
-  hipLaunchKernelGGL((pack_w2_frag_kernel<T, S>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, w2, out, C);
+  hipLaunchKernelGGL((pack_w2_frag_kernel<T, S>), dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, w2, gamma, out, C);
   GCV_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -381,8 +381,23 @@ template <typename T> struct NetImpl : NetBase {
             k.fc2_wf = (T*)st.raw((size_t)4 * C * C * sizeof(T));
             if (!k.fc1_wf || !k.fc2_wf) { set_error("hipMalloc failed for the fragment-major fc1 / fc2"); return -5; }
             GCV_TRY((launch_pack_w1_frag<T, T>(k.fc1_w, k.fc1_wf, C, nullptr)));
-            GCV_TRY((launch_pack_w2_frag<T, T>(k.fc2_w, k.fc2_wf, C, nullptr)));
-            GCV_CHECK_HIP(hipDeviceSynchronize());
+            {
+              // the block's layer scale is folded into the packed fc2 (mlp_pair.h): packed from the fp32 source so that
+              // gamma * W2 is rounded to T once
+              std::vector<float> v, gv;
+              GCV_TRY(fetch(w, b + "mlp.fc2.weight", (int64_t)4 * C * C, v));
+              GCV_TRY(fetch(w, b + "gamma", C, gv));
+              struct DevBuf {                      // freed on every exit path
+                float* p = nullptr;
+                ~DevBuf() { if (p) (void)hipFree(p); }
+              } tmp, tg;
+              GCV_CHECK_HIP(hipMalloc((void**)&tmp.p, v.size() * 4));
+              GCV_CHECK_HIP(hipMalloc((void**)&tg.p, gv.size() * 4));
+              GCV_CHECK_HIP(hipMemcpy(tmp.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+              GCV_CHECK_HIP(hipMemcpy(tg.p, gv.data(), gv.size() * 4, hipMemcpyHostToDevice));
+              GCV_TRY((launch_pack_w2_frag<T, float>(tmp.p, tg.p, k.fc2_wf, C, nullptr)));
+              GCV_CHECK_HIP(hipDeviceSynchronize());
+            }
           }
           if ((C <= 192 && !k.fc_wp) || (C == 384 && use_fused_mlp384)) {   // stages with a round-2 fused MLP kernel in use
             std::vector<float> v;

@@ -131,9 +131,16 @@ def convnext_block(sd, p, x, store=True, mfma_taps=False):
     y = _q(F.layer_norm(y, (c,), sd[p + "norm.weight"], sd[p + "norm.bias"], LN_EPS_CONVNEXT))
     y = F.linear(y, _q(sd[p + "mlp.fc1.weight"]), sd[p + "mlp.fc1.bias"])
     y = _q(F.gelu(y))
-    y = F.linear(y, _q(sd[p + "mlp.fc2.weight"]), sd[p + "mlp.fc2.bias"])
-    y = y.permute(0, 3, 1, 2)
-    y = y * sd[p + "gamma"].reshape(1, -1, 1, 1)
+    if _STORE is not None and c == 384:
+        # the C = 384 kernel pair folds the layer scale into the packed fc2 (csrc/mlp_pair.h pack_w2_frag_kernel): the MFMA
+        # operand is gamma * W2 rounded once to the storage dtype, the bias term gamma * b2 stays fp32
+        g = sd[p + "gamma"]
+        y = F.linear(y, _q(g[:, None] * sd[p + "mlp.fc2.weight"]), g * sd[p + "mlp.fc2.bias"])
+        y = y.permute(0, 3, 1, 2)
+    else:
+        y = F.linear(y, _q(sd[p + "mlp.fc2.weight"]), sd[p + "mlp.fc2.bias"])
+        y = y.permute(0, 3, 1, 2)
+        y = y * sd[p + "gamma"].reshape(1, -1, 1, 1)
     return _q(y + x) if store else y + x
 
 

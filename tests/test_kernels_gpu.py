@@ -177,6 +177,7 @@ def test_stem_conv4x4_layernorm(dt, layout, res):
 @pytest.mark.parametrize("dt", ALL)
 @pytest.mark.parametrize("C,H,n", [(96, 56, 2), (96, 28, 3), (192, 28, 2), (192, 14, 1), (384, 14, 2), (384, 7, 3),
                                    (768, 7, 2), (768, 3, 3),
+                                   (768, 1, 5), (768, 2, 3), (768, 4, 2),      # whole-map kernel of the tiny stage-3 maps (with (768, 3, 3))
                                    # launches of more than 128 seven-row bands keep seven-row bands (the large-batch rule);
                                    # the few-image cases above run the two- to four-row bands of small launches
                                    (96, 56, 17), (384, 14, 70),
