@@ -28,6 +28,8 @@
 // fp32 accumulation, exact fp32 taps, LayerNorm statistics in fp32 for every storage dtype.  DESIGN.md section 4 has
 // the measurements and the dead ends.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace gcv {
@@ -128,6 +130,11 @@ dwconv7_ln_roll_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*
   if (tid < NCONV) {
     // ================================================================== tap waves
     const int sl = tid / C, c = tid - sl * C;
+    // ES0 / ES1: halo columns of this strip that can hold data.  Two strips of 7 at multiples of 64 channels (the 14-pixel
+    // maps at C = 192 / 384: whole waves per strip) know at compile time that their outer three columns are the zero apron:
+    // 6 of a tap row's 49 FMAs and 3 of its 13 LDS reads are padding there, as in the single full-width strip.
+    auto tap_waves = [&](auto s0c, auto s1c) {
+    constexpr int ES0 = decltype(s0c)::value, ES1 = decltype(s1c)::value;
     float w[49];
 #pragma unroll
     for (int k = 0; k < 49; ++k) w[k] = wdw[k * C + c];
@@ -151,7 +158,7 @@ dwconv7_ln_roll_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*
                  "+v"(nxt[4]), "+v"(nxt[5]), "+v"(nxt[6]), "+v"(nxt[7]), "+v"(nxt[8]), "+v"(nxt[9]), "+v"(nxt[10]), \
                  "+v"(nxt[11]), "+v"(nxt[12])::"memory")
     GCV_LDS_BARRIER();                                 // P1: rows 0 and 1 are staged
-    dw_read_row<C, S0, S1>(nxt, in_addr);              // row it0 (slot 0)
+    dw_read_row<C, ES0, ES1>(nxt, in_addr);              // row it0 (slot 0)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(nxt[0]), "+v"(nxt[1]), "+v"(nxt[2]), "+v"(nxt[3]), "+v"(nxt[4]), "+v"(nxt[5]),
                  "+v"(nxt[6]), "+v"(nxt[7]), "+v"(nxt[8]), "+v"(nxt[9]), "+v"(nxt[10]), "+v"(nxt[11]), "+v"(nxt[12])::"memory");
     int pslot = 1;                                     // ring slot of input row it + 1
@@ -164,8 +171,8 @@ dwconv7_ln_roll_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*
           float cur[13];
           DW_STAMP(tid == 0 && it == GCV_DW_STAMP_IT, 0); DW_STAMP(tid == 320 && it == GCV_DW_STAMP_IT, 16); DW_STAMP(tid == NCONV - 64 && it == GCV_DW_STAMP_IT, 21);
 #pragma unroll
-          for (int s = S0; s < S1; ++s) cur[s] = nxt[s];
-          if (!(GCV_DWR_ABLATE & 1)) dw_read_row<C, S0, S1>(nxt, in_addr + (uint32_t)(pslot * IN_ROW * 4));
+          for (int s = ES0; s < ES1; ++s) cur[s] = nxt[s];
+          if (!(GCV_DWR_ABLATE & 1)) dw_read_row<C, ES0, ES1>(nxt, in_addr + (uint32_t)(pslot * IN_ROW * 4));
           pslot = (pslot == 2) ? 0 : pslot + 1;
           // tap rows in the order 6, 0, 1 .. 5: row 6 completes an output row, which is written to LDS at once so that
           // the 84 ds_write_b32 of the workgroup (64 B/clk: ~340 cycles) drain under the other six rows' FMAs
@@ -190,7 +197,7 @@ dwconv7_ln_roll_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*
               for (int ox = 0; ox < 7; ++ox)
 #pragma unroll
                 for (int kx = 0; kx < 7; ++kx)
-                  if (ox + kx >= S0 && ox + kx < S1)
+                  if (ox + kx >= ES0 && ox + kx < ES1)
                     acc[slot][ox] = fmaf(cur[ox + kx], w[ky * 7 + kx], acc[slot][ox]);
             }
           };
@@ -219,6 +226,13 @@ dwconv7_ln_roll_kernel(const T* __restrict__ x, const float* __restrict__ wdw /*
       }
     }
 #undef GCV_DW_BARRIER_NXT
+    };
+    if constexpr (NS == 2 && C % 64 == 0) {
+      if (__builtin_amdgcn_readfirstlane(sl) == 0) tap_waves(std::integral_constant<int, 3>{}, std::integral_constant<int, 13>{});
+      else tap_waves(std::integral_constant<int, 0>{}, std::integral_constant<int, 10>{});
+    } else {
+      tap_waves(std::integral_constant<int, S0>{}, std::integral_constant<int, S1>{});
+    }
   } else {
     // ================================================================== staging + LayerNorm waves
     __builtin_amdgcn_s_setprio(3);                     // one latency-bound wave per SIMD beside three FMA-bound ones

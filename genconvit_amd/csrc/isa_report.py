@@ -47,7 +47,7 @@ def demangle(n):
 # bytes of scratch per lane a kernel may use: (regex on the MANGLED name — the image has no demangler that knows DF16_ —,
 # bytes); first match wins, default 0
 SCRATCH_BUDGET = [
-    (r"pw2f_kernelI\w+?Li384ELi384ELi3ELi8EE", 56),     # 13 dwords: the five DMA source pointers around the K loop call sites
+    (r"pw2f_kernelI\w+?Li384ELi384ELi3ELi8EE", 28),     # 6 dwords outside the steady-state loop
     (r"xs_mlp_kernelI\w+?Li192ELb[01]EE", 20),          # 4 dwords in the pass prologue
     (r"dwconv7_ln_roll_kernelI\w+?Li96ELi4EE", 8),      # 1 dword
     (r"dwconv7_ln_kernelI\w+?Li768EE", 88),             # generic kernel of the 3x3 maps of the 112-pixel pass

@@ -336,10 +336,9 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) xs_pw1_kernel(const MlpPairAr
 template <int C, int BN, int D, int TB = 8> struct Pw2fSmem {
   static constexpr int kStage = (TB + BN / 32) * 2048;     // TB token blocks + BN/32 channel blocks, one 32-deep K chunk
   static constexpr int kBG = D * kStage;                   // gamma * b2 of the tile's BN channels
-  // residual rows on their way into the accumulators (TRICKLE, below): two 1 KB slots per wave
-  static constexpr bool kTrickle = BN == C && D == 3 && TB == 8;
+  // residual rows on their way into the accumulators (TRICKLE, below): D - 1 slots of 1 KB per wave
   static constexpr int kRes = kBG + BN * 4;
-  static constexpr int bytes = kRes + (kTrickle ? 8 * 2048 : 0);
+  static constexpr int bytes = kRes + 8 * (D - 1) * 1024;
   static_assert(bytes <= 160 * 1024, "LDS of a CU");
 };
 
@@ -452,17 +451,18 @@ __global__ void __launch_bounds__(512, 2) pw2f_kernel(const MlpPairArgs a) {
       }
   }
 
-  // ---- TRICKLE (full-width tiles): the residual rows do not wait for the epilogue.  Round 3 read them there, four
-  // dependent round trips to HBM per wave with nothing beside them: 20 of the kernel's 83 us, all 196 workgroups at once.
-  // Here piece r = (token block i, channel block j, half pr) of the wave's 128 x 96 residual tile — one 16-byte piece per
-  // lane, the layout the accumulator exchange below wants — is fetched by LDS-DMA into one of two private 1 KB slots at K
-  // step r (registers: none; it is issued BEFORE the step's ring pieces, so the counted wait of step r + 2, which retires
-  // the ring pieces of step r, retires it too) and added into acc[i][j] at step r + 2.  24 pieces, 48 steps.
-  constexpr bool TRK = SM::kTrickle;
+  // ---- TRICKLE: the residual rows do not wait for the epilogue.  Round 3 read them there, four dependent round trips to
+  // HBM per wave with nothing beside them: 20 of the 256 x 384 kernel's 83 us, all 196 workgroups at once.
+  // Here piece r = (token block i, channel block j, half pr) of the wave's residual tile — one 16-byte piece per lane, the
+  // layout the accumulator exchange below wants — is fetched by LDS-DMA into one of D - 1 private 1 KB slots at K step r
+  // (registers: none; it is issued BEFORE the step's ring pieces, so the counted wait of step r + D - 1, which retires the
+  // ring pieces issued at step r, retires it too) and added into acc[i][j] at step r + D - 1.  2 MI NI pieces (24 at the
+  // 128 x 96 wave tile), NKC = 48 steps.
   constexpr int NPR = MI * NI * 2;
-  static_assert(!TRK || NPR + 2 < NKC - (D - 1), "the trickle ends inside the steady-state loop");
+  constexpr int RD = D - 1;                                // steps between a piece's issue and its use = its slots
+  static_assert(NPR + RD <= NKC - (D - 1), "the trickle ends inside the steady-state part of the K loop");
   const T* const Rp = (const T*)a.resid;
-  unsigned char* const sres = smem + SM::kRes + wave * 2048;
+  unsigned char* const sres = smem + SM::kRes + wave * (RD * 1024);
   const int ncol0 = nb0 * 32 + wn * 96;                    // first channel of this wave
   auto row_of = [&](int i) { return (int64_t)(tb0 + wm * MI + i) * 32 + lr; };
   auto issue_res = [&](int r) {
@@ -471,12 +471,12 @@ __global__ void __launch_bounds__(512, 2) pw2f_kernel(const MlpPairArgs a) {
     const int64_t mmc = mm < a.M ? mm : (int64_t)a.M - 1;
     const T* src = Rp + mmc * C + ncol0 + 32 * j + 16 * pr + 8 * lh;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(sres + (r & 1) * 1024), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(sres + (r % RD) * 1024), 16, 0, 0);
   };
   auto take_res = [&](auto rc) {                           // acc[i][j][8 pr .. 8 pr + 7] += the landed piece
     constexpr int r = decltype(rc)::value;
     constexpr int i = r / (2 * NI), j = (r >> 1) % NI, pr = r & 1;
-    const u32x4 rw = *(const u32x4*)(sres + (r & 1) * 1024 + lane * 16);
+    const u32x4 rw = *(const u32x4*)(sres + (r % RD) * 1024 + lane * 16);
     const auto rx = __builtin_amdgcn_permlane32_swap(rw[0], rw[2], false, false);
     const auto ry = __builtin_amdgcn_permlane32_swap(rw[1], rw[3], false, false);
     const t4 rq[2] = {__builtin_bit_cast(t4, uint2{rx[0], ry[0]}), __builtin_bit_cast(t4, uint2{rx[1], ry[1]})};
@@ -539,34 +539,24 @@ __global__ void __launch_bounds__(512, 2) pw2f_kernel(const MlpPairArgs a) {
   // steady state: chunk kc has landed when at most (D-2) younger stages are outstanding; its slot's previous tenant
   // (chunk kc-1's neighbour in the ring) was left by every wave before this barrier, so the refill goes there
   constexpr int NSTEADY = NKC - (D - 1);
-  int kc0 = 0;
-  if constexpr (TRK) {
-    // steps 0 .. NPR + 1: one residual piece per step rides in front of the ring pieces, so a stage is PPW + 1 operations
-    // (at step NPR + 1 the two younger stages hold one residual piece between them: the larger count would let the ring
-    // pieces of step NPR + 1's chunk pass unretired, hence the loop ends at NPR and the tail uses the plain count, which
-    // is merely early for one step)
-    constexpr int WAITR = (D - 2) * (PPW + 1);
-    // (straight-line code: which accumulator block a step feeds must be a constant — a run-time switch over the 24 blocks
-    //  made hipcc spill 761 registers)
-    pw2f_static_for<0, NPR + 1>([&](auto kcc) {
-      constexpr int kc = decltype(kcc)::value;
-      if constexpr (kc == 0) GCV_XS_WAIT(WAITN);           // the younger stage is a prologue stage: no residual piece in it
-      else GCV_XS_WAIT(WAITR);
-      if constexpr (kc >= 2) take_res(std::integral_constant<int, kc - 2>{});
-      if constexpr (kc < NPR) issue_res(kc);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(std::true_type{});
-    });
-    kc0 = NPR + 1;
-  }
+  // steps 0 .. NPR + RD - 1, straight-line (which accumulator block a step feeds must be a constant: a run-time switch over
+  // the 24 blocks made hipcc spill 761 registers): a residual piece rides in front of the ring pieces of steps 0 .. NPR - 1,
+  // so the D - 2 younger stages a step leaves in flight hold PPW operations each plus one for every such step among them
+  pw2f_static_for<0, NPR + RD>([&](auto kcc) {
+    constexpr int kc = decltype(kcc)::value;
+    constexpr int lo = kc - (D - 2) > 0 ? kc - (D - 2) : 0, hi = kc < NPR ? kc : NPR;   // younger steps [lo, hi) issued a piece
+    constexpr int WAITR = (D - 2) * PPW + (hi > lo ? hi - lo : 0);
+    GCV_XS_WAIT(WAITR);
+    if constexpr (kc >= RD) take_res(std::integral_constant<int, kc - RD>{});
+    if constexpr (kc < NPR) issue_res(kc);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(std::true_type{});
+  });
 #pragma unroll 1
-  for (int kc = kc0; kc < NSTEADY; ++kc) {
+  for (int kc = NPR + RD; kc < NSTEADY; ++kc) {
     if (kc >= 8 && kc < 16) P2_STAMP(4 * (kc - 8));
     GCV_XS_WAIT(WAITN);
     if (kc >= 8 && kc < 16) P2_STAMP(4 * (kc - 8) + 1);
-    if constexpr (TRK) {
-      if (kc == NPR + 1) take_res(std::integral_constant<int, NPR - 1>{});
-    }
     compute(std::true_type{});
     if (kc >= 8 && kc < 16) P2_STAMP(4 * (kc - 8) + 3);
   }
@@ -577,41 +567,23 @@ __global__ void __launch_bounds__(512, 2) pw2f_kernel(const MlpPairArgs a) {
   }
 
   P2_STAMP(41);
-  // ---- epilogue, token-major rows.  A row's 16-byte piece (channels 16 pr + 8 lh .. + 7 of block j) is stored (and, without
-  // the trickle, loaded) whole; v_permlane32_swap (its own inverse) converts between that and the accumulator's (8q + 4lh)
-  // halves.  TRICKLE: the accumulator already is the result.  Otherwise out = resid + acc (acc started at gamma * b2 and W2f
-  // carries gamma), the residual rows fetched one token block ahead of their use.
+  // ---- epilogue, token-major rows: the accumulator already is the result (it started at gamma * b2, W2f carries gamma, the
+  // residual came in under the K loop).  A row's 16-byte piece (channels 16 pr + 8 lh .. + 7 of block j) is stored whole;
+  // v_permlane32_swap converts the accumulator's (8q + 4lh) halves into it.
   T* Op = (T*)a.out;
-  auto load_res = [&](int i, u32x4 (&rr)[NI][2]) {
-    const int64_t mm = row_of(i);
-    const int64_t mmc = mm < a.M ? mm : (int64_t)a.M - 1;
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr) rr[j][pr] = *(const u32x4*)(Rp + mmc * C + ncol0 + 32 * j + 16 * pr + 8 * lh);
-  };
-  auto finish = [&](int i, const u32x4 (&rr)[NI][2]) {
+  for (int i = 0; i < MI; ++i) {
     const int64_t mm = row_of(i);
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
-        t4 rq[2];
-        if constexpr (!TRK) {
-          const u32x4 rw = rr[j][pr];
-          const auto rx = __builtin_amdgcn_permlane32_swap(rw[0], rw[2], false, false);
-          const auto ry = __builtin_amdgcn_permlane32_swap(rw[1], rw[3], false, false);
-          rq[0] = __builtin_bit_cast(t4, uint2{rx[0], ry[0]});
-          rq[1] = __builtin_bit_cast(t4, uint2{rx[1], ry[1]});
-        }
         uint2 pk[2];
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-          const int q = 2 * pr + d;
           t4 o4;
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            o4[e] = from_f<T>(TRK ? acc[i][j][4 * q + e] : acc[i][j][4 * q + e] + to_f(rq[d][e]));
+          for (int e = 0; e < 4; ++e) o4[e] = from_f<T>(acc[i][j][4 * (2 * pr + d) + e]);
           pk[d] = __builtin_bit_cast(uint2, o4);
         }
         const auto sx = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
@@ -619,20 +591,6 @@ __global__ void __launch_bounds__(512, 2) pw2f_kernel(const MlpPairArgs a) {
         const u32x4 w = {sx[0], sy[0], sx[1], sy[1]};
         if (mm < a.M) *(u32x4*)(Op + mm * C + ncol0 + 32 * j + 16 * pr + 8 * lh) = w;
       }
-  };
-  u32x4 rA[NI][2], rB[NI][2];
-  if constexpr (TRK) {
-#pragma unroll
-    for (int i = 0; i < MI; ++i) finish(i, rA);
-  } else {
-    load_res(0, rA);
-#pragma unroll
-    for (int i = 0; i < MI; i += 2) {
-      if (i + 1 < MI) load_res(i + 1, rB);
-      finish(i, rA);
-      if (i + 2 < MI) load_res(i + 2, rA);
-      if (i + 1 < MI) finish(i + 1, rB);
-    }
   }
   P2_STAMP(42);
 }

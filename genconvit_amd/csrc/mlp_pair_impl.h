@@ -58,29 +58,24 @@ template <typename T, int C> static int launch_xs_pw1_c(const MlpPairArgs& a, hi
   return 0;
 }
 
+template <typename T, int C, int BN, int D, int TB> static int launch_pw2f_cfg(const MlpPairArgs& a, hipStream_t s) {
+  constexpr int SMEM = Pw2fSmem<C, BN, D, TB>::bytes;
+  GCV_ENSURE_LDS((pw2f_kernel<T, C, BN, D, TB>), SMEM);
+  hipLaunchKernelGGL((pw2f_kernel<T, C, BN, D, TB>), dim3(cdiv(a.M, 32 * TB) * (C / BN)), dim3(512), SMEM, s, a);
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// Ring depths: stages of one 32-deep K chunk + (D - 1) KB per wave of residual staging in 160 KB of LDS — 256 x 384 tiles
+// 3 x 40 KB, 256 x 192 tiles 4 x 28 KB, 128 x 192 tiles 5 x 20 KB
 template <typename T, int C> static int launch_pw2f_c(const MlpPairArgs& a, hipStream_t s) {
   const int ntm = cdiv(a.M, 256);
   // full-width tiles halve the operand bytes per FLOP but need >= ~0.7 x 256 of them to keep the chip busy
-  if (ntm >= 180) {
-    constexpr int BN = C, D = 3;
-    constexpr int SMEM = Pw2fSmem<C, BN, D>::bytes;
-    GCV_ENSURE_LDS((pw2f_kernel<T, C, BN, D>), SMEM);
-    hipLaunchKernelGGL((pw2f_kernel<T, C, BN, D>), dim3(ntm), dim3(512), SMEM, s, a);
-  } else if (ntm * (C / 192) >= 128) {
-    constexpr int BN = 192, D = 5;
-    constexpr int SMEM = Pw2fSmem<C, BN, D>::bytes;
-    GCV_ENSURE_LDS((pw2f_kernel<T, C, BN, D>), SMEM);
-    hipLaunchKernelGGL((pw2f_kernel<T, C, BN, D>), dim3(ntm * (C / BN)), dim3(512), SMEM, s, a);
-  } else {
-    // a few thousand tokens (batches of 32, the 112-pixel pass): 128-token tiles, twice the workgroups, each with half the
-    // MFMAs per K chunk
-    constexpr int BN = 192, D = 6, TB = 4;
-    constexpr int SMEM = Pw2fSmem<C, BN, D, TB>::bytes;
-    GCV_ENSURE_LDS((pw2f_kernel<T, C, BN, D, TB>), SMEM);
-    hipLaunchKernelGGL((pw2f_kernel<T, C, BN, D, TB>), dim3(cdiv(a.M, 32 * TB) * (C / BN)), dim3(512), SMEM, s, a);
-  }
-  GCV_CHECK_HIP(hipGetLastError());
-  return 0;
+  if (ntm >= 180) return launch_pw2f_cfg<T, C, C, 3, 8>(a, s);
+  if (ntm * (C / 192) >= 128) return launch_pw2f_cfg<T, C, 192, 4, 8>(a, s);
+  // a few thousand tokens (batches of 32, the 112-pixel pass): 128-token tiles, twice the workgroups, each with half the
+  // MFMAs per K chunk
+  return launch_pw2f_cfg<T, C, 192, 5, 4>(a, s);
 }
 
 template <typename T> int launch_xs_pw1(const MlpPairArgs& a, int C, hipStream_t s) {
