@@ -144,6 +144,27 @@ __global__ void __launch_bounds__(256, 2) gemm_glds_kernel(const GemmArgs g) {
     pre = *(const f32x4*)(g.gamma + n0 + 4 * (tid - BN / 4));
   }
 
+  // the residual rows of the tile (EPI_RESID: 24 independent 8-byte loads per lane) are issued here as well, ahead of every
+  // DMA: they land under the K loop instead of costing the epilogue a round trip to HBM (48 registers held until then; the
+  // kernel runs two workgroups per CU at K >= 512, where this epilogue is used, so 256 are available)
+  typedef T t4 __attribute__((ext_vector_type(4)));
+  t4 rres[EPI == EPI_RESID ? MI : 1][EPI == EPI_RESID ? NI : 1][4];
+  auto load_resid = [&]() {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = m0 + wm0 + i * 32 + lr;
+      const int64_t mm = m < g.M ? m : g.M - 1;
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          rres[i][j][q] = *(const t4*)((const T*)g.resid + mm * g.ldc + n0 + wn0 + j * 32 + 8 * q + 4 * lh);
+    }
+  };
+  // (the 64-byte-row ring runs three workgroups per CU, 168 registers each: there the loads stay in the epilogue)
+  constexpr bool RESID_EARLY = EPI == EPI_RESID && BKB == 128;
+  if (RESID_EARLY && !(GCV_GLDS_ABLATE & 4)) load_resid();
+
   // ---- pipeline: stages kt+1 .. kt+S-2 stay in flight while stage kt is consumed ----
 #pragma unroll
   for (int s = 0; s < S - 1; ++s)
@@ -169,23 +190,10 @@ __global__ void __launch_bounds__(256, 2) gemm_glds_kernel(const GemmArgs g) {
   // issued before the barrier) or already in registers (bias / gamma), so it pays ONE memory latency, not one
   // per 4-channel group.
   constexpr int SROW = GldsSmem<T, BKB>::kEpiRow;
-  typedef T t4 __attribute__((ext_vector_type(4)));
   uint32_t* sC = reinterpret_cast<uint32_t*>(smem);
   float* sBG = reinterpret_cast<float*>(smem + GldsSmem<T, BKB>::kEpiBG);
   T* Cp = (T*)g.C;
-  t4 rres[EPI == EPI_RESID ? MI : 1][EPI == EPI_RESID ? NI : 1][4];
-  if (EPI == EPI_RESID && !(GCV_GLDS_ABLATE & 4)) {
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = m0 + wm0 + i * 32 + lr;
-      const int64_t mm = m < g.M ? m : g.M - 1;
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          rres[i][j][q] = *(const t4*)((const T*)g.resid + mm * g.ldc + n0 + wn0 + j * 32 + 8 * q + 4 * lh);
-    }
-  }
+  if (EPI == EPI_RESID && !RESID_EARLY && !(GCV_GLDS_ABLATE & 4)) load_resid();
   if (tid < BN / 2) *(f32x4*)(sBG + 4 * tid) = pre;
   __syncthreads();
 #pragma unroll
