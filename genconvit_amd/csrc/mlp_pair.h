@@ -554,11 +554,11 @@ __global__ void __launch_bounds__(512, 2) pw2f_kernel(const MlpPairArgs a) {
   });
 #pragma unroll 1
   for (int kc = NPR + RD; kc < NSTEADY; ++kc) {
-    if (kc >= 8 && kc < 16) P2_STAMP(4 * (kc - 8));
+    if (kc >= 32 && kc < 40) P2_STAMP(4 * (kc - 32));     // (diagnostic builds: steps 32 .. 39 are behind the trickle)
     GCV_XS_WAIT(WAITN);
-    if (kc >= 8 && kc < 16) P2_STAMP(4 * (kc - 8) + 1);
+    if (kc >= 32 && kc < 40) { P2_STAMP(4 * (kc - 32) + 1); P2_STAMP(4 * (kc - 32) + 2); }
     compute(std::true_type{});
-    if (kc >= 8 && kc < 16) P2_STAMP(4 * (kc - 8) + 3);
+    if (kc >= 32 && kc < 40) P2_STAMP(4 * (kc - 32) + 3);
   }
 #pragma unroll
   for (int kc = NSTEADY; kc < NKC; ++kc) {                 // drain: nothing left to issue
