@@ -168,6 +168,10 @@ typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 // y = fma(p, 2, max(fp16(x), 0)), one v_pk_max_i16 + one v_pk_fma_f16 per PAIR instead of v_max_i32 + v_fma_mix per value
 // and a v_cvt_pk afterwards): x is rounded to fp16 before the ReLU part, as the reference's own .half() pipeline does with
 // the Linear output (rms 3.25e-4).  7 vector instructions per hidden value instead of 9.5; bf16 storage: 8.5.
+// NaN: max(x, 0) is an integer max of the bit pattern (v_pk_max_i16 / v_max_i32), so a NaN with the sign bit set comes out as
+// the finite value 2 p(4) while a positive NaN propagates (|x| clamps to 4.0, the ReLU part stays NaN).  Accepted on this path:
+// a NaN in a hidden activation means the input or the weights were already corrupt, and the fp32-storage path (exact erf, float
+// max) propagates every NaN — compare the two dtypes when chasing one (tests/test_kernels_gpu.py test_gelu_nan_behaviour_is_documented).
 struct GeluH16 {                       // polynomial state of NP pairs of values between the three phases
   static constexpr int DEG = 8;
   template <int NP> struct State { h16x2 xh[NP], t[NP], p[NP]; };

@@ -18,7 +18,8 @@ Checks (run by the Makefile on every build):
  2. registers with a load in flight behind the compiler's back.  Inline-asm ds_read_* / global_load_* results are not
     tracked by SIInsertWaitcnts; correctness rests on no instruction touching the destination registers until the
     inline-asm s_waitcnt that retires them (lgkmcnt for ds_read, vmcnt for global_load).  A register-allocator copy,
-    spill or any other use in between would read a value that has not landed: flagged as an error.
+    spill or any other use in between would read a value that has not landed: flagged as an error.  Loop bodies are scanned a
+    second time with the loads that are in flight at their back-edge.
 
  3. the register cliff.  Several kernels sit at their register budget by design (dwconv_mfma.h: 42 tap operands + 56
     accumulators + 12 gathered operands at the 128-register budget of a 16-wave workgroup; pw2f_kernel: 192 accumulators at
@@ -129,6 +130,8 @@ def kernels(text):
             if t.startswith('.Lfunc_end'):
                 yield name, body
                 name = None
+            elif re.match(r'^\.LBB\w+:$', t):
+                body.append((ln, t, False))               # a label: check 2 follows backward branches to it
             continue
         body.append((ln, t, in_asm))
         if t.startswith('s_endpgm'):
@@ -160,38 +163,53 @@ def check_file(path):
                 if dst and regs_of(dst[0]) & data:
                     findings.append(f"{path}:{ln}: {short}: `{t}` (SGPR soffset) has its data registers written by "
                                     f"`{t2}` {ln2 - ln} line(s) later — wide-store hazard (isa_report.py check 1)")
-        # ---- check 2
-        pending = {}                                      # reg -> ('lgkm'|'vm', line of the load)
-        for ln, t, in_asm in body:
-            op = t.split()[0]
-            rest = t[len(op):]
-            ops = split_ops(rest)
-            if in_asm and (op.startswith('ds_read') or op.startswith('global_load_dword') or op.startswith('buffer_load_dword')) \
-                    and 'lds' not in t.split():
-                kind = 'lgkm' if op.startswith('ds_read') else 'vm'
-                for r in regs_of(ops[0]) if ops else ():
-                    pending[r] = (kind, ln)
-                continue
-            if in_asm and op == 's_waitcnt':
-                # a counted vmcnt(N) wait in this code base retires everything older than the N youngest operations; the
-                # inline-asm loads it guards are always older (see the kernels), so any asm vmcnt / lgkmcnt wait clears
-                if 'lgkmcnt' in t:
-                    pending = {r: v for r, v in pending.items() if v[0] != 'lgkm'}
-                if 'vmcnt' in t:
-                    pending = {r: v for r, v in pending.items() if v[0] != 'vm'}
-                continue
-            if not pending or in_asm:
-                continue
-            used = set()
-            for o in ops:
-                used |= regs_of(o)
-            hit = used & set(pending)
-            if hit:
-                r = sorted(hit)[0]
-                findings.append(f"{path}:{ln}: {short}: `{t}` touches {r[0]}{r[1]} while the inline-asm load of line "
-                                f"{pending[r][1]} is still in flight (no asm s_waitcnt between) — isa_report.py check 2")
-                for h in hit:
-                    pending.pop(h, None)
+        # ---- check 2: a linear scan, plus one more pass over every loop body with the pending set its back-edge carries
+        # (a load issued at the end of a loop body and retired at its head is otherwise only checked through the copy of
+        # the same load in front of the loop)
+        labels = {t[:-1]: i for i, (_, t, _) in enumerate(body) if t.endswith(':')}
+
+        def scan(lo, hi, pending, carried):
+            for idx in range(lo, hi):
+                ln, t, in_asm = body[idx]
+                if t.endswith(':'):
+                    continue
+                op = t.split()[0]
+                rest = t[len(op):]
+                ops = split_ops(rest)
+                if in_asm and (op.startswith('ds_read') or op.startswith('global_load_dword') or op.startswith('buffer_load_dword')) \
+                        and 'lds' not in t.split():
+                    kind = 'lgkm' if op.startswith('ds_read') else 'vm'
+                    for r in regs_of(ops[0]) if ops else ():
+                        pending[r] = (kind, ln)
+                    continue
+                if in_asm and op == 's_waitcnt':
+                    # a counted vmcnt(N) wait in this code base retires everything older than the N youngest operations; the
+                    # inline-asm loads it guards are always older (see the kernels), so any asm vmcnt / lgkmcnt wait clears
+                    if 'lgkmcnt' in t:
+                        pending = {r: v for r, v in pending.items() if v[0] != 'lgkm'}
+                    if 'vmcnt' in t:
+                        pending = {r: v for r, v in pending.items() if v[0] != 'vm'}
+                    continue
+                if not carried and pending and op.startswith('s_cbranch') or (not carried and pending and op == 's_branch'):
+                    tgt = ops[0] if ops else ''
+                    if tgt in labels and labels[tgt] < idx:          # back-edge: the loop body again, with what is in flight now
+                        scan(labels[tgt], idx, dict(pending), True)
+                if not pending or in_asm:
+                    continue
+                used = set()
+                for o in ops:
+                    used |= regs_of(o)
+                hit = used & set(pending)
+                if hit:
+                    r = sorted(hit)[0]
+                    how = " (carried over the loop's back-edge)" if carried else ""
+                    findings.append(f"{path}:{ln}: {short}: `{t}` touches {r[0]}{r[1]} while the inline-asm load of line "
+                                    f"{pending[r][1]} is still in flight{how} (no asm s_waitcnt between) — isa_report.py check 2")
+                    for h in hit:
+                        pending.pop(h, None)
+            return pending
+
+        scan(0, len(body), {}, False)
     return findings
 
 

@@ -78,6 +78,42 @@ def test_oracle_dispatch_thresholds_equal_the_product_headers():
     assert 63 * 56 < cpu_ref.DW_MFMA_MIN_IMAGE_ROWS <= 64 * 56
 
 
+def test_isa_report_checks_on_synthetic_assembly(tmp_path):
+    """csrc/isa_report.py runs on every build; its three checks on small hand-written listings: the wide-store hazard,
+    an inline-asm load whose register is touched before the asm s_waitcnt — also when the load sits at the END of a loop body
+    and the touch at its head (the back-edge pass) — and the scratch budget."""
+    import importlib.util
+    spec_ = importlib.util.spec_from_file_location("isa_report", os.path.join(REPO, "genconvit_amd", "csrc", "isa_report.py"))
+    isa = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(isa)
+
+    def listing(body, scratch=0):
+        return ("_Z4testv:\n" + body + "\ts_endpgm\n.Lfunc_end0:\n"
+                "  - .agpr_count:     0\n    .group_segment_fixed_size: 0\n    .name:           _Z4testv\n"
+                f"    .private_segment_fixed_size: {scratch}\n    .sgpr_count:     10\n    .vgpr_count:     8\n"
+                "    .vgpr_spill_count: 0\n")
+
+    def findings(body, scratch=0):
+        f = tmp_path / "k.s"
+        f.write_text(listing(body, scratch))
+        return isa.check_file(str(f)) + isa.check_scratch(str(f))
+
+    clean = ("\t;;#ASMSTART\n\tglobal_load_dwordx4 v[4:7], v[0:1], off\n\t;;#ASMEND\n"
+             "\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n\t;;#ASMEND\n\tv_add_f32 v1, v5, v5\n")
+    assert findings(clean) == []
+    early = ("\t;;#ASMSTART\n\tglobal_load_dwordx4 v[4:7], v[0:1], off\n\t;;#ASMEND\n\tv_add_f32 v1, v5, v5\n")
+    assert len(findings(early)) == 1 and "check 2" in findings(early)[0]
+    loop = (".LBB0_1:\n\tv_add_f32 v1, v5, v5\n\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n\t;;#ASMEND\n\tv_mov_b32 v2, v5\n"
+            "\t;;#ASMSTART\n\tglobal_load_dwordx4 v[4:7], v[0:1], off\n\t;;#ASMEND\n\ts_cbranch_scc1 .LBB0_1\n")
+    got = findings(loop)
+    assert len(got) == 1 and "back-edge" in got[0], got
+    loop_ok = loop.replace(".LBB0_1:\n\tv_add_f32 v1, v5, v5\n", ".LBB0_1:\n\tv_add_f32 v1, v3, v3\n")
+    assert findings(loop_ok) == []
+    store = "\tbuffer_store_dwordx4 v[10:13], v2, s[4:7], s2 offen\n\tv_mov_b32 v10, v3\n"
+    assert len(findings(store)) == 1 and "check 1" in findings(store)[0]
+    assert len(findings(clean, scratch=64)) == 1 and "check 3" in findings(clean, scratch=64)[0]
+
+
 # ----------------------------------------------------------------------------- host mirror API
 def test_config_keys():
     from genconvit_amd.model.config import load_config
