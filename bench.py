@@ -302,7 +302,7 @@ def main():
         if "cnx.dwconv7_ln" in fam:
             families.append(entry("cnx.dwconv7_ln", fam["cnx.dwconv7_ln"], "hbm", "dwconv7_ln"))
         if "vae.mu_gemm_splitk" in fam:          # weight-streaming GEMM: 25088 x 12544 weights read once per batch
-            families.append(entry("vae.mu_gemm_splitk", fam["vae.mu_gemm_splitk"], "hbm", None))
+            families.append(entry("vae.mu_gemm_splitk", fam["vae.mu_gemm_splitk"], "hbm", "mu_gemm"))
         roof_families = families
 
     log("kernel profile pass done")

@@ -47,6 +47,26 @@ hipEvent_t Profiler::get_event() {
 Profiler::~Profiler() {
   for (hipEvent_t e : pool) (void)hipEventDestroy(e);
 }
+
+namespace {
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+      pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+      if (push && pop) return;
+      push = nullptr; pop = nullptr;
+    }
+  }
+};
+Roctx& roctx() { static Roctx r; return r; }
+}  // namespace
+void roctx_push(const char* tag) { if (roctx().push) (void)roctx().push(tag); }
+void roctx_pop() { if (roctx().pop) (void)roctx().pop(); }
 }  // namespace gcv
 
 using namespace gcv;

@@ -25,6 +25,13 @@ struct ProfRecord {
   hipEvent_t e0, e1;
 };
 
+// roctx ranges: while a handle's profiling is on, every tagged launch is also bracketed by a
+// roctxRangePushA(tag) / roctxRangePop pair, so `rocprofv3 --marker-trace --kernel-trace` groups the kernels by the same
+// semantic tags gcv_profile_report() uses.  The marker library is bound at run time (rocprofiler-sdk's roctx, then the legacy
+// libroctx64) and only when profiling is switched on; without it the calls are no-ops.
+void roctx_push(const char* tag);
+void roctx_pop();
+
 struct Profiler {
   bool enabled = false;
   std::vector<ProfRecord> recs;

@@ -219,9 +219,11 @@ template <typename T> struct NetImpl : NetBase {
     r.bytes = bytes;
     r.e0 = prof.get_event();
     r.e1 = prof.get_event();
+    roctx_push(tag);
     GCV_CHECK_HIP(hipEventRecord(r.e0, cur));
     const int rc = f();
     GCV_CHECK_HIP(hipEventRecord(r.e1, cur));
+    roctx_pop();
     prof.recs.push_back(r);
     return rc;
   }

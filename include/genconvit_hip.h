@@ -148,7 +148,9 @@ int  gcv_allgather_logits(gcv_comm* c, const float* local, int n_local, float* a
 /* Per-launch timing with HIP events on the launch stream.  After gcv_profile_enable(h,1) every
  * kernel launch of the following forwards is bracketed by events; gcv_profile_report() waits for
  * them and returns a JSON array aggregated by op tag (launches, ms, algorithmic flops / bytes)
- * and clears the records.  The returned string lives until the next call on the handle. */
+ * and clears the records.  The returned string lives until the next call on the handle.  While profiling is on, every
+ * tagged launch is also a roctx range of the same name (roctxRangePushA / roctxRangePop, bound at run time from
+ * librocprofiler-sdk-roctx / libroctx64 when present), so `rocprofv3 --marker-trace --kernel-trace` groups kernels by op. */
 int gcv_profile_enable(gcv_handle* h, int on);
 const char* gcv_profile_report(gcv_handle* h);
 

@@ -38,6 +38,9 @@ def fam(k):
                                     re.search(r"gemm_glds_kernel<[^,]+, 1,", k) or re.search(r"gemm_glds_kernel<[^,]+, 0, 2,", k)):
         return "mfma_gemm"
     if "dwconv7_ln" in k: return "dwconv7_ln"
+    # the split-K GEMM (EPI 4: the 8th template argument of gemm_kernel) is the mu GEMM of the VAE encoder (the var GEMM runs
+    # only when the KL term is asked for, which bench.py does not)
+    if re.search(r"gemm_kernelI\w+?(?:Li\d+E){6}Li4E", k) or re.search(r"gemm_kernel<(?:[^,]+, ){7}4,", k): return "mu_gemm"
     return "other"
 res = {}
 for k in set(fe) | set(wr):
@@ -60,7 +63,8 @@ if line is None: sys.exit("no bench line in " + out + "/fetch.log")
 expected = {}
 for e in [line.get("roofline")] + (line.get("roofline_families") or []):
     if not e: continue
-    key = "mfma_gemm" if e["kernel"].startswith("mfma_gemm") else ("dwconv7_ln" if "dwconv" in e["kernel"] else None)
+    key = "mfma_gemm" if e["kernel"].startswith("mfma_gemm") else ("dwconv7_ln" if "dwconv" in e["kernel"] else
+                                                                   ("mu_gemm" if "mu_gemm" in e["kernel"] else None))
     if key: expected[key] = e["launches_per_step"]
 bad = []
 for key, lps in expected.items():

@@ -23,3 +23,18 @@ rm -rf $O/pmc/fetch $O/pmc/write
 echo traffic done
 for t in mlp384 pw1_768 pw2_768 dwconv384; do bash profiles/pmc_pass.sh gpurun_out/r04/sq_$t $t > $O/pmc_sq_$t.txt 2>&1; rm -rf $O/sq_$t; done
 echo all done
+# roctx ranges of the profiled pass (gcv_profile_enable): marker trace of a short serial run, ranges counted per tag
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --marker-trace --kernel-trace --output-format csv -d $O/marker -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-concurrent --profile-steps 1 > $O/marker.log 2>&1 )
+python3 - $O <<'PY'
+import csv, glob, sys, collections
+o = sys.argv[1]
+c = collections.Counter()
+for f in glob.glob(o + "/marker/*/*marker_api_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        c[r.get("Function") or r.get("Name") or "?"] += 1
+open(o + "/roctx_ranges_by_tag.txt", "w").write("# roctx ranges recorded by rocprofv3 --marker-trace over one profiled genconvit B=128 fp16 step (serial schedule)\n" +
+    "".join(f"{n:6d}  {k}\n" for k, n in sorted(c.items(), key=lambda kv: -kv[1])))
+print(open(o + "/roctx_ranges_by_tag.txt").read()[:1500])
+PY
+rm -rf $O/marker
+echo marker done
