@@ -31,8 +31,9 @@ template <typename T> int launch_ln_patchify(const T* x, const float* w, const f
                                              int W, int C, float eps, hipStream_t s);
 template <typename T> int launch_layernorm_rows(const T* x, const float* w, const float* b, T* out, int64_t rows,
                                                 int C, float eps, hipStream_t s);
+// seg_n > 0: image b of the launch -> output row (b % seg_n) * row_stride + row0 + b / seg_n (see pool_ln_kernel)
 template <typename T> int launch_pool_ln(const T* x, const float* w, const float* b, T* out, int nimg, int HW, int C,
-                                         float eps, hipStream_t s);
+                                         float eps, hipStream_t s, int seg_n = 0, int row_stride = 1, int row0 = 0);
 template <typename T> int launch_conv3_first(const T* x, int64_t sb, int64_t sc, int64_t sy, int64_t sx,
                                              const float* wp, const float* bias, T* out, int nimg, int H, int W,
                                              bool pool, int act, hipStream_t s);

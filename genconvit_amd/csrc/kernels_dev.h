@@ -906,9 +906,13 @@ __global__ void __launch_bounds__(256) mean_tokens_kernel(const T* __restrict__ 
 template <typename T>
 __global__ void __launch_bounds__(256) pool_ln_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ bvec, T* __restrict__ out, int HW,
-                                                      int C /*768*/, float eps) {
+                                                      int C /*768*/, float eps, int seg_n, int row_stride, int row0) {
+  // image b of the launch (its passes one after the other, seg_n images each) -> output row
+  // (b % seg_n) * row_stride + row0 + b / seg_n: with row_stride = the network's number of passes the rows of one frame's
+  // passes are neighbours, and the classifier GEMM over all of them writes the (B, passes * 1000) feature matrix in one launch
   __shared__ float red[8];
   const int b = blockIdx.x, tid = threadIdx.x;
+  const int orow = (b % seg_n) * row_stride + row0 + b / seg_n;
   const T* src = x + (int64_t)b * HW * C;
   float m[3] = {0.f, 0.f, 0.f};
   for (int p = 0; p < HW; ++p) {
@@ -932,7 +936,7 @@ __global__ void __launch_bounds__(256) pool_ln_kernel(const T* __restrict__ x, c
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const int c = tid + 256 * k;
-    out[(int64_t)b * C + c] = from_f<T>((m[k] - mean) * rstd * w[c] + bvec[c]);
+    out[(int64_t)orow * C + c] = from_f<T>((m[k] - mean) * rstd * w[c] + bvec[c]);
   }
 }
 

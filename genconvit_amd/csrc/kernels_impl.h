@@ -115,9 +115,10 @@ int launch_layernorm_rows(const T* x, const float* w, const float* b, T* out, in
 
 template <typename T>
 int launch_pool_ln(const T* x, const float* w, const float* b, T* out, int nimg, int HW, int C, float eps,
-                   hipStream_t s) {
+                   hipStream_t s, int seg_n, int row_stride, int row0) {
   GCV_REQUIRE(C == 768 && nimg > 0 && HW > 0, "pool_ln: C == 768");
-  hipLaunchKernelGGL((pool_ln_kernel<T>), dim3(nimg), dim3(256), 0, s, x, w, b, out, HW, C, eps);
+  if (seg_n <= 0) { seg_n = nimg; row_stride = 1; row0 = 0; }            // plain order: image b -> row b
+  hipLaunchKernelGGL((pool_ln_kernel<T>), dim3(nimg), dim3(256), 0, s, x, w, b, out, HW, C, eps, seg_n, row_stride, row0);
   GCV_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -251,7 +252,7 @@ template <typename T> int launch_preprocess(const unsigned char* u8, T* out, int
                                     int, int, float, hipStream_t);                                                    \
   template int launch_ln_patchify<T>(const T*, const float*, const float*, T*, int, int, int, int, float, hipStream_t); \
   template int launch_layernorm_rows<T>(const T*, const float*, const float*, T*, int64_t, int, float, hipStream_t);  \
-  template int launch_pool_ln<T>(const T*, const float*, const float*, T*, int, int, int, float, hipStream_t);        \
+  template int launch_pool_ln<T>(const T*, const float*, const float*, T*, int, int, int, float, hipStream_t, int, int, int); \
   template int launch_conv3_first<T>(const T*, int64_t, int64_t, int64_t, int64_t, const float*, const float*, T*,    \
                                      int, int, int, bool, int, hipStream_t);                                          \
   template int launch_convt2_small<T>(const T*, const float*, const float*, T*, int, int, int, int, hipStream_t);     \

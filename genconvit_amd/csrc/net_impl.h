@@ -704,24 +704,41 @@ template <typename T> struct NetImpl : NetBase {
         GCV_TRY(gemm("cnx.pw2_scale_res", g2, A_PLAIN, EPI_RESID));
       }
     }
+    // pooling + LayerNorm: one launch over neighbouring segments of one map size (their tokens are contiguous).  When the
+    // passes are the column blocks of one feature matrix (ED, VAE: equal frame counts, out = base + 1000 s, one leading
+    // dimension, one activation) the pooled rows are written frame-major — row nseg * frame + pass — so that ONE classifier
+    // GEMM over all nseg * n rows with ldc = 1000 writes the (n, nseg * 1000) matrix (round 4; one launch per pass before)
+    bool one_fc = nseg > 1;
+    for (int s = 1; s < nseg && one_fc; ++s)
+      one_fc = segs[s].n == segs[0].n && segs[s].out == segs[0].out + 1000 * s && segs[s].out_ld == 1000 * nseg &&
+               segs[0].out_ld == 1000 * nseg && segs[s].act == segs[0].act;
     int no = 0;
     for (int s = 0; s < nseg; ++s) {
-      // pooling + LayerNorm: one launch over neighbouring segments of one map size (their tokens and their pooled rows are
-      // contiguous); the classifier GEMM stays per segment (each writes its own column block of the feature matrix)
       if (s == 0 || h[s] * wd[s] != h[s - 1] * wd[s - 1]) {
         int e = s, nimg = 0;
         int64_t mm = 0;
         while (e < nseg && h[e] * wd[e] == h[s] * wd[s]) { nimg += segs[e].n; mm += m[e]; ++e; }
         GCV_TRY(run("cnx.pool_ln", 2.0 * mm * 768, sizeof(T) * (double)mm * 768, [&] {
+          if (one_fc)
+            return launch_pool_ln<T>(X + moff[s] * 768, w.head_lnw, w.head_lnb, Pool, nimg, h[s] * wd[s], 768, 1e-6f, cur,
+                                     segs[0].n, nseg, s);
           return launch_pool_ln<T>(X + moff[s] * 768, w.head_lnw, w.head_lnb, Pool + (int64_t)no * 768, nimg, h[s] * wd[s],
                                    768, 1e-6f, cur);
         }));
       }
-      GemmArgs g{};
-      g.A = Pool + (int64_t)no * 768; g.lda = 768; g.Wt = w.head_fc_w; g.C = segs[s].out; g.ldc = segs[s].out_ld;
-      g.bias = w.head_fc_b; g.M = segs[s].n; g.N = 1000; g.K = 768; g.act = segs[s].act; g.splitk = 1;
-      GCV_TRY(gemm("cnx.head_fc", g, A_PLAIN, EPI_BIAS_ACT));
+      if (!one_fc) {
+        GemmArgs g{};
+        g.A = Pool + (int64_t)no * 768; g.lda = 768; g.Wt = w.head_fc_w; g.C = segs[s].out; g.ldc = segs[s].out_ld;
+        g.bias = w.head_fc_b; g.M = segs[s].n; g.N = 1000; g.K = 768; g.act = segs[s].act; g.splitk = 1;
+        GCV_TRY(gemm("cnx.head_fc", g, A_PLAIN, EPI_BIAS_ACT));
+      }
       no += segs[s].n;
+    }
+    if (one_fc) {
+      GemmArgs g{};
+      g.A = Pool; g.lda = 768; g.Wt = w.head_fc_w; g.C = segs[0].out; g.ldc = 1000;
+      g.bias = w.head_fc_b; g.M = ntot; g.N = 1000; g.K = 768; g.act = segs[0].act; g.splitk = 1;
+      GCV_TRY(gemm("cnx.head_fc", g, A_PLAIN, EPI_BIAS_ACT));
     }
     if (!keep) arena.release(mk);
     return 0;
