@@ -529,6 +529,11 @@ int gcv_k_head_tail(int dtype, const void* h, const float* w, const float* bias,
   DISPATCH_DT(dtype, launch_head_tail<T>((const T*)h, w, bias, logits, B, K, (hipStream_t)s));
 }
 
+int gcv_k_head_tail_splitk(int dtype, const float* partial, int splitk, const float* b1, int act, const float* w,
+                           const float* bias, float* logits, int B, int K, gcv_stream s) {
+  DISPATCH_DT(dtype, launch_head_tail_splitk<T>(partial, splitk, b1, act, w, bias, logits, B, K, (hipStream_t)s));
+}
+
 int gcv_k_resize_mse(int dtype, const void* xhat, const void* img, void* recon, float* msepart, float* mse, int B,
                      gcv_stream s) {
   DISPATCH_DT(dtype, launch_resize_mse<T>((const T*)xhat, (const T*)img, (T*)recon, msepart, mse, B, (hipStream_t)s));

@@ -43,6 +43,9 @@ template <typename T> int launch_reparam(const float* partial, int splitk, const
                                          float* mu_out, T* z_nhwc, int B, int N, hipStream_t s);
 template <typename T> int launch_head_tail(const T* h, const float* w, const float* bias, float* logits, int B, int K,
                                            hipStream_t s);
+// the same with the hidden layer's split-K partials (S, B, K) fp32 reduced on the way in: h = act(sum + b1)
+template <typename T> int launch_head_tail_splitk(const float* partial, int S, const float* b1, int act, const float* w,
+                                                  const float* bias, float* logits, int B, int K, hipStream_t s);
 template <typename T> int launch_resize_mse(const T* xhat, const T* img, T* recon, float* msepart, float* mse, int B,
                                             hipStream_t s);
 template <typename T> int launch_swin_window_attn(const T* qkv, const float* rpb, T* out, int nimg, int H, int W, int C,

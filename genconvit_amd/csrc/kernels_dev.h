@@ -1285,6 +1285,36 @@ __global__ void __launch_bounds__(256) head_tail_kernel(const T* __restrict__ h,
   }
 }
 
+// K8 with the hidden layer's split-K reduce folded in: h = act(sum_s partial[s] + b1) (rounded to T, as the stored hidden
+// activation was), logits = h . W2^T + b2.  The 2000 -> 500 layer of <= 512 rows is a chain of 32 K tiles on a handful of
+// workgroups when it runs as one GEMM (37 us at 128 rows); split eight ways it is 4 tiles deep, and its reduction costs
+// nothing here.  (model/genconvit_ed.py:87, model/genconvit_vae.py:114: fc2(act(fc(act(x)))).)
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) head_tail_splitk_kernel(const float* __restrict__ partial, int S,
+                                                               const float* __restrict__ b1, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ logits,
+                                                               int B, int K) {
+  // one workgroup per row: every thread owns hidden units tid, tid + 256, .. and sums their S partials with independent
+  // loads (a wave per row walked 8 x 8 dependent loads: 22 us for 128 rows)
+  __shared__ float red[2][4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float a0 = 0.0f, a1 = 0.0f;
+  for (int k = tid; k < K; k += 256) {
+    float v = b1[k];
+    const float* p = partial + (int64_t)b * K + k;
+#pragma unroll 8
+    for (int s = 0; s < S; ++s) v += p[(int64_t)s * B * K];
+    v = to_f(from_f<T>(act_fn<ACT>(v)));
+    a0 = fmaf(v, w[k], a0);
+    a1 = fmaf(v, w[K + k], a1);
+  }
+  a0 = wave_sum(a0);
+  a1 = wave_sum(a1);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = a0; red[1][tid >> 6] = a1; }
+  __syncthreads();
+  if (tid < 2) logits[2 * b + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3] + bias[tid];
+}
+
 // ------------------------------------------------------------------ K13/K14 bilinear x2 + MSE
 // x_hat NHWC (B,112,112,3) -> recon NCHW (B,3,224,224) (nullable) ; msepart[b][blk] partial sums of
 // (recon - img)^2 over the block's pixels (nullable), img NCHW (B,3,224,224).

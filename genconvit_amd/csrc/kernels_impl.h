@@ -186,6 +186,22 @@ int launch_head_tail(const T* h, const float* w, const float* bias, float* logit
 }
 
 template <typename T>
+int launch_head_tail_splitk(const float* partial, int S, const float* b1, int act, const float* w, const float* bias,
+                            float* logits, int B, int K, hipStream_t s) {
+  GCV_REQUIRE(B > 0 && S >= 1, "head_tail_splitk: empty");
+#define GCV_HT(A)                                                                                                    \
+  case A: hipLaunchKernelGGL((head_tail_splitk_kernel<T, A>), dim3(B), dim3(256), 0, s, partial, S, b1, w, bias, \
+                             logits, B, K); break;
+  switch (act) {
+    GCV_HT(ACT_NONE) GCV_HT(ACT_RELU) GCV_HT(ACT_GELU) GCV_HT(ACT_LEAKY)
+    default: set_error("bad activation code"); return -2;
+  }
+#undef GCV_HT
+  GCV_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
 int launch_resize_mse(const T* xhat, const T* img, T* recon, float* msepart, float* mse, int B, hipStream_t s) {
   GCV_REQUIRE(B > 0, "resize: empty");
   const int nblk = 224 * 224 / 256;   // 196
@@ -258,6 +274,7 @@ template <typename T> int launch_preprocess(const unsigned char* u8, T* out, int
   template int launch_convt2_small<T>(const T*, const float*, const float*, T*, int, int, int, int, hipStream_t);     \
   template int launch_reparam<T>(const float*, int, const float*, const float*, float*, T*, int, int, hipStream_t);   \
   template int launch_head_tail<T>(const T*, const float*, const float*, float*, int, int, hipStream_t);              \
+  template int launch_head_tail_splitk<T>(const float*, int, const float*, int, const float*, const float*, float*, int, int, hipStream_t); \
   template int launch_resize_mse<T>(const T*, const T*, T*, float*, float*, int, hipStream_t);                        \
   template int launch_swin_window_attn<T>(const T*, const float*, T*, int, int, int, int, int, int, hipStream_t);     \
   template int launch_patch_merge_ln<T>(const T*, const float*, const float*, T*, int, int, int, int, float, hipStream_t); \

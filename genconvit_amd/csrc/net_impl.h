@@ -745,14 +745,18 @@ template <typename T> struct NetImpl : NetBase {
   }
 
   int run_head(const HeadW<T>& hw, const T* feat, int B, int act, float* logits) {
+    // fc (2000 -> 500) eight ways split-K into fp32 partials; their sum, the bias, the activation and fc2 (500 -> 2) are one
+    // small kernel (round 4: as one GEMM the layer was a chain of 32 K tiles on eight workgroups, 37 us at 128 rows)
+    const int SK = 8, KPS = 256;
     const size_t mk = arena.mark();
-    T* hbuf = arena.get<T>((int64_t)B * 500 + 8);
+    float* part = arena.get<float>((int64_t)SK * B * 500 + 8);
     GemmArgs g{};
-    g.A = feat; g.lda = 2000; g.Wt = hw.fc_w; g.C = hbuf; g.ldc = 500; g.bias = hw.fc_b;
-    g.M = B; g.N = 500; g.K = 2000; g.act = act; g.splitk = 1;
-    GCV_TRY(gemm("head.fc", g, A_PLAIN, EPI_BIAS_ACT));
-    GCV_TRY(run("head.fc2", 2.0 * B * 2 * 500, sizeof(T) * (double)B * 500,
-                [&] { return launch_head_tail<T>(hbuf, hw.fc2_w, hw.fc2_b, logits, B, 500, cur); }));
+    g.A = feat; g.lda = 2000; g.Wt = hw.fc_w; g.partial = part;
+    g.M = B; g.N = 500; g.K = 2000; g.act = ACT_NONE; g.splitk = SK; g.k_per_split = KPS;
+    GCV_TRY(gemm("head.fc", g, A_PLAIN, EPI_SPLITK));
+    GCV_TRY(run("head.fc2", 2.0 * B * 2 * 500, 4.0 * (double)SK * B * 500, [&] {
+      return launch_head_tail_splitk<T>(part, SK, hw.fc_b, act, hw.fc2_w, hw.fc2_b, logits, B, 500, cur);
+    }));
     arena.release(mk);
     return 0;
   }

@@ -185,6 +185,11 @@ int gcv_k_reparam(int dtype, const float* partial, int splitk, const float* bias
                   void* z_nhwc, int B, int N, gcv_stream s);
 int gcv_k_head_tail(int dtype, const void* h, const float* w, const float* bias, float* logits, int B, int K,
                     gcv_stream s);
+/* The head as the networks run it (model/genconvit_ed.py:87, model/genconvit_vae.py:114: fc2(act(fc(.)))): the hidden layer's
+ * split-K partials (splitk, B, K) fp32 are reduced on the way in, h = act(sum + b1) rounded to the storage dtype, then
+ * logits = h . w^T + bias with w (2, K), in one kernel.  act: GCV_ACT_* code. */
+int gcv_k_head_tail_splitk(int dtype, const float* partial, int splitk, const float* b1, int act, const float* w,
+                           const float* bias, float* logits, int B, int K, gcv_stream s);
 int gcv_k_resize_mse(int dtype, const void* xhat, const void* img, void* recon, float* msepart, float* mse, int B,
                      gcv_stream s);
 

@@ -341,6 +341,24 @@ def test_head_tail(dt):
 
 
 @pytest.mark.parametrize("dt", ALL)
+@pytest.mark.parametrize("act", [1, 2])
+def test_head_tail_with_splitk_reduce(dt, act):
+    """The head as the networks run it: fc's split-K partials summed, + bias, ReLU (vae) / exact GELU (ed), rounded to the
+    storage dtype, then fc2 (model/genconvit_ed.py:87, model/genconvit_vae.py:114)."""
+    dtype = DTYPES[dt]
+    B, K, S = 37, 500, 8
+    part = rnd((S, B, K), 1, 0.5)
+    b1 = rnd((K,), 2, 0.1)
+    w, b = rnd((2, K), 3, 0.05), rnd((2,), 4, 0.1)
+    h = q(act_ref(part.sum(0) + b1, act), dtype)
+    out = torch.zeros((B, 2), dtype=torch.float32, device=dev())
+    kutil.call("gcv_k_head_tail_splitk", _lib.dtype_code(dtype), ptr(D(part)), S, ptr(D(b1)), act, ptr(D(w)), ptr(D(b)),
+               ptr(out), B, K)
+    # (a hidden value that sits on a rounding boundary of the storage dtype may round the other way: one ulp of h times w)
+    assert_close(out, h @ w.t() + b, {torch.float32: 1e-5, torch.float16: 2e-4, torch.bfloat16: 2e-3}[dtype], "head tail split-K")
+
+
+@pytest.mark.parametrize("dt", ALL)
 def test_bilinear_resize_and_mse(dt):
     """transforms.Resize((224,224)) of x_hat (genconvit_vae.py:116) + per-frame MSE (train/train_vae.py:24)."""
     dtype = DTYPES[dt]
