@@ -234,6 +234,15 @@ def main():
         dt = float(t.item())
     assert torch.isfinite(out).all()
     log(f"timed region: {a.steps} steps in {dt:.3f} s")
+    # diagnostic, NOT `value`: the same step with a device synchronisation behind every step — what a caller that reads each
+    # result before submitting the next batch (pred_vid) sees.  The timed region above lets the host run ahead, so every
+    # step's launches are queued before the GPU reaches them; here the enqueue time of a step is exposed.
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+        torch.cuda.synchronize()
+    synced_ms = (time.perf_counter() - t1) / a.steps * 1e3
+    log(f"synchronised after every step: {synced_ms:.3f} ms per step")
 
     # ---- roofline of the dominant kernel family: HIP events around every launch (separate steps so
     #      the event records do not perturb the timed region) --------------------------------------
@@ -361,6 +370,7 @@ def main():
                        "net": a.net, "frames_per_gpu": a.batch, "global_batch": n_global,
                        "parallelism": f"frame-shard x{world}", "algorithmic_gflop_per_frame": GFLOP_PER_FRAME[a.net]},
             "roofline": roof, "roofline_families": roof_families, "cpu_baseline": cpu,
+            "ms_per_step_synchronised": round(synced_ms, 4),    # diagnostic: a device sync behind every step (not `value`)
             "rccl_ranks": comm["rccl_ranks"] if comm else 0,
             "comm": comm if comm else {"backend": None, "allgather_path": "none (one process, no collective)", "rccl_ranks": 0,
                                        "devices": [f"{torch.cuda.get_device_name(device)} (cuda:{local_rank})"]},

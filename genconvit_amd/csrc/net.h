@@ -3,6 +3,7 @@
 #pragma once
 #include <map>
 #include <memory>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,9 @@ struct NetBase {
   int max_batch = 0;
   Profiler prof;
   bool in_ensemble = false;   // set by gcv_genconvit_forward around vae_forward: the VAE shares the GPU with the ED network
+  // host-side enqueue order of the ensemble (gcv_genconvit_forward): called by vae_forward once its encoder -> mu ->
+  // decoder chain is enqueued and before its backbone pass, to enqueue the ED network on its own stream in between
+  std::function<int()> after_chain;
   virtual ~NetBase() {}
   virtual int init() = 0;
   virtual int load_ed(const TensorMap& w) = 0;

@@ -926,6 +926,7 @@ template <typename T> struct NetImpl : NetBase {
     GCV_TRY(run("vae.dec4_convT_leaky", 2.0 * B * 56 * 56 * 16 * 12,
                 sizeof(T) * (double)B * (16 * 56 * 56 + 3 * 112 * 112),
                 [&] { return launch_convt2_small<T>(d3, vae.dec4_w, vae.dec4_b, xhat, B, 56, 56, ACT_LEAKY, cur); }));
+    if (after_chain && !arena.dry) GCV_TRY(after_chain());
     if (split) { GCV_TRY(run_convnext(bb_vae, &segs[1], 1, true)); }
     else { GCV_TRY(run_convnext(bb_vae, segs, 2)); }
     join.now();
